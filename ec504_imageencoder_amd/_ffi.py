@@ -1,0 +1,84 @@
+"""ctypes binding of the in-tree libencoder.so (include/mpeg1_hip.h + include/encoder.h).
+
+The library is the product: hand-written HIP kernels for gfx950 behind a C-ABI.  There is no CPU
+fallback — if the shared object is missing or cannot be loaded this module raises.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libencoder.so")
+
+MODE_STRICT, MODE_FULL = 0, 1
+OK, E_ARG, E_UNENCODABLE, E_NOSPACE, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4, -5
+STATUS_UNENCODABLE, STATUS_NOSPACE = 1, 2
+
+_u8p = C.POINTER(C.c_uint8)
+
+# every symbol include/mpeg1_hip.h declares (tests check that the library exports all of them)
+MPEG1_HIP_SYMBOLS = [
+    "m1v_device_count", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
+    "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
+    "m1v_coefficients_device", "m1v_convert_device", "m1v_subsample_device", "m1v_synth_device",
+    "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words",
+]
+
+
+class EncoderLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EncoderLibraryMissing(
+            f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.m1v_device_count.restype = C.c_int
+    L.m1v_last_error.restype = C.c_char_p
+    L.m1v_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.m1v_create.restype = C.c_int
+    L.m1v_destroy.argtypes = [vp]
+    L.m1v_destroy.restype = None
+    for name in ("m1v_strips", "m1v_mb_rows"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_int
+    for name in ("m1v_frame_bound", "m1v_frame_bytes_in"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_size_t
+    L.m1v_file_prolog.argtypes = [_u8p]
+    L.m1v_file_prolog.restype = C.c_size_t
+    L.m1v_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]
+    L.m1v_encode_device.restype = C.c_int
+    L.m1v_encode_host.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    L.m1v_encode_host.restype = C.c_long
+    L.m1v_coefficients_device.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.m1v_coefficients_device.restype = C.c_int
+    L.m1v_convert_device.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.m1v_convert_device.restype = C.c_int
+    L.m1v_subsample_device.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.m1v_subsample_device.restype = C.c_int
+    L.m1v_synth_device.argtypes = [vp, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64, vp]
+    L.m1v_synth_device.restype = C.c_int
+    L.m1v_profile_enable.argtypes = [vp, C.c_int]
+    L.m1v_profile_enable.restype = C.c_int
+    L.m1v_profile_read.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.m1v_profile_read.restype = C.c_int
+    L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
+    L.m1v_debug_set_lds_words.restype = C.c_int
+    if hasattr(L, "mpeg_encode_procedure"):
+        L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.mpeg_encode_procedure.restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().m1v_last_error().decode(errors="replace")

@@ -1,0 +1,123 @@
+/* include/mpeg1_hip.h — C-ABI of the MI355X (gfx950) MPEG-1 I-frame hot path.
+ *
+ * This is the boundary a host program (C, JNI, cgo, ctypes ...) binds.  Plain pointers and sizes
+ * only; no C++ or torch types.  Implemented by libencoder.so (ec504_imageencoder_amd/csrc/).
+ *
+ * What each entry point replaces in the reference (eburhansjah/ec504_ImageEncoder, paths under
+ * /root/reference):
+ *
+ *   m1v_encode_device / m1v_encode_host
+ *       the per-frame body of mpeg_encode_procedure, include/encoder.h:196-458:
+ *       packet/sequence/GOP/picture headers (source/mpeg1_enc.c:47-129), convert_rgb_to_ycbcr
+ *       (source/image_processing.c:68), the slice -> macroblock -> block loops (encoder.h:238-444:
+ *       extract_8x8_block :138, fast_DCT :192, quantization :349, zigzag_scanning :373,
+ *       run_length_encode :703, encode_block_header_i source/mpeg1_blk.c:67, VLC_encode
+ *       image_processing.c:400, encode_blk_coeff source/vlc.c:315, bit_vector.c appends),
+ *       the strip zero-padding (encoder.h:442), the 16-bit length back-patch (encoder.h:448-453)
+ *       and the 4 trailing bytes (encoder.h:456-458).
+ *   m1v_coefficients_device    fast_DCT + quantization + zigzag_scanning only (BASELINE config 2)
+ *   m1v_convert_device         convert_rgb_to_ycbcr, image_processing.c:68-110 (feeds the .bit files,
+ *                              write_to_bitstream image_processing.c:753)
+ *   m1v_subsample_device       subsampling_420, image_processing.c:114-133 (dead in the reference's
+ *                              data flow; provided for completeness)
+ *   m1v_file_prolog            mpeg1_file_header + mpeg1_sys_header, mpeg1_enc.c:7-44 / encoder.h:86-89
+ *   m1v_synth_device           no reference counterpart: device-side synthetic frames for benchmarks
+ *
+ * The coarse, drop-in entry point mpeg_encode_procedure() is declared in include/encoder.h.
+ *
+ * All *_device entry points are asynchronous on `stream` (a hipStream_t passed as void*, NULL =
+ * the default stream) and take DEVICE pointers.  Return value: M1V_OK or a negative M1V_E_*.
+ */
+#ifndef MPEG1_HIP_H
+#define MPEG1_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Region covered by the macroblock loops:
+ *   STRICT  x in [0,96), y in [0,144): the literals at encoder.h:238 / :248 (byte-identical to the
+ *           unmodified reference)
+ *   FULL    x in [0, W & ~15), y in [0, H & ~15): the reference with those two literals restored */
+enum { M1V_MODE_STRICT = 0, M1V_MODE_FULL = 1 };
+
+enum {
+    M1V_OK = 0,
+    M1V_E_ARG = -1,         /* bad argument / geometry the reference would read out of bounds with  */
+    M1V_E_UNENCODABLE = -2, /* an emitted AC level has |level| >= 256 (reference: vlc.c:349 -> NULL
+                               -> segfault); output of the batch is undefined                       */
+    M1V_E_NOSPACE = -3,     /* output buffer too small                                             */
+    M1V_E_HIP = -4,         /* HIP runtime error, see m1v_last_error()                             */
+    M1V_E_NODEVICE = -5     /* no usable gfx950 device                                             */
+};
+
+/* bits of the device status word (m1v_encode_device's d_status) */
+enum { M1V_STATUS_UNENCODABLE = 1u, M1V_STATUS_NOSPACE = 2u };
+
+typedef struct m1v_encoder m1v_encoder;
+
+int m1v_device_count(void);
+const char *m1v_last_error(void); /* thread-local, never NULL */
+
+/* One encoder = one device, one picture geometry, one quality factor.  max_frames bounds the batch
+ * a single m1v_encode_* call may carry (scratch is sized for it). */
+int m1v_create(m1v_encoder **out, int device, int width, int height, int channels,
+               int quality_factor, int mode, int max_frames);
+void m1v_destroy(m1v_encoder *enc);
+
+/* geometry helpers */
+int m1v_strips(const m1v_encoder *enc);          /* x_extent / 16 */
+int m1v_mb_rows(const m1v_encoder *enc);         /* y_extent / 16 */
+size_t m1v_frame_bound(const m1v_encoder *enc);  /* worst-case bytes of one frame record */
+size_t m1v_frame_bytes_in(const m1v_encoder *enc); /* width*height*channels */
+
+/* PACK(12)+SYS(15), written once per file.  Returns 27. */
+size_t m1v_file_prolog(uint8_t out[27]);
+
+/* n_frames frames, contiguous in d_rgb (interleaved, width*height*channels bytes each), to
+ * contiguous frame records in d_out.  first_frame_index is the global index of frame 0 of the batch
+ * (it drives the `hour` fields, encoder.h:42,475-484).
+ *   d_frame_sizes  uint64[n_frames] bytes of each record (may be NULL)
+ *   d_total        uint64[1] total bytes written (may be NULL)
+ *   d_status       uint32[1] OR of M1V_STATUS_* (may be NULL) */
+int m1v_encode_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int first_frame_index,
+                      uint8_t *d_out, size_t out_cap, uint64_t *d_frame_sizes, uint64_t *d_total,
+                      uint32_t *d_status, void *stream);
+
+/* Host-buffer convenience (PCIe inclusive, synchronous): returns total bytes or negative M1V_E_*. */
+long m1v_encode_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,
+                     uint8_t *out, size_t out_cap, uint64_t *frame_sizes);
+
+/* The 64 zigzag-ordered quantised levels of every visited block, int16, in emission order
+ * [frame][strip][macroblock][Y0 Y1 Y2 Y3 Cb Cr][64]. */
+int m1v_coefficients_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int16_t *d_coeffs,
+                            void *stream);
+
+/* Full-resolution planes per frame: Y[w*h] Cb[w*h] Cr[w*h] (3*w*h bytes per frame). */
+int m1v_convert_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, uint8_t *d_planes,
+                       void *stream);
+/* 2x2 truncated mean of one Cb and one Cr plane (even width and height). */
+int m1v_subsample_device(m1v_encoder *enc, const uint8_t *d_cb, const uint8_t *d_cr,
+                         uint8_t *d_cb_sub, uint8_t *d_cr_sub, void *stream);
+
+/* byte k of frame f = byte (k & 7) of splitmix64(seed + f*0x9E3779B97F4A7C15 + (k >> 3)), little-endian */
+int m1v_synth_device(uint8_t *d_rgb, size_t bytes_per_frame, int n_frames, uint64_t seed,
+                     uint64_t first_frame_index, void *stream);
+
+/* Kernel timing by HIP events recorded on the launch stream around the dominant kernel
+ * (encode_strips).  enable!=0 starts collecting; m1v_profile_read synchronises the recorded events
+ * and returns launches/total milliseconds since the last read. */
+int m1v_profile_enable(m1v_encoder *enc, int enable);
+int m1v_profile_read(m1v_encoder *enc, int *launches, double *total_ms);
+
+/* Test hook: capacity in 32-bit words of the per-strip LDS bit buffer (0 = default).  A tiny value
+ * forces the global-memory fallback path so that tests can cover it. */
+int m1v_debug_set_lds_words(m1v_encoder *enc, int words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
