@@ -1,0 +1,328 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C-ABI of include/mpeg1_hip.h,
+against the oracle on the same seeded inputs and against the committed golden vectors.
+Bar: bit-exact (integer / byte work; the fp64 colour conversion is truncated to u8)."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+import golden_io as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _enc(W, H, qf=12, mode="full", channels=3, max_frames=8):
+    from ec504_imageencoder_amd import Mpeg1Encoder
+    return Mpeg1Encoder(W, H, qf, mode, channels=channels, max_frames=max_frames)
+
+
+def _omode(orc, mode):
+    return orc.MODE_FULL if mode == "full" else orc.MODE_STRICT
+
+
+def test_library_is_the_hip_build(torch_cuda):
+    from ec504_imageencoder_amd import _ffi
+    assert _ffi.lib().m1v_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "ec504_imageencoder_amd/libencoder.so" in maps
+
+
+def test_synth_matches_oracle_definition(torch_cuda, orc):
+    for W, H, C in ((16, 16, 3), (33, 7, 3), (352, 288, 3), (5, 3, 4)):
+        enc_geom = _enc(max(W, 16), max(H, 16), channels=C)  # only used for its synth helper signature
+        enc_geom.width, enc_geom.height, enc_geom.frame_bytes_in = W, H, W * H * C
+        got = enc_geom.synth(3, seed=77, first_frame_index=9).cpu().numpy()
+        assert np.array_equal(got, orc.synth_frames(3, W, H, seed=77, first_index=9, channels=C))
+        enc_geom.close()
+
+
+def test_colour_conversion_exhaustive_2_24(torch_cuda, orc):
+    """Every RGB triple through k_convert vs the oracle AND vs the reference-generated SHA-256."""
+    torch = torch_cuda
+    want = G.load_json("colour_exhaustive.json")["sha256"]
+    enc = _enc(4096, 4096)  # 2^24 pixels in one frame
+    v = torch.arange(1 << 24, dtype=torch.int32, device="cuda")
+    rgb = torch.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], -1).to(torch.uint8).reshape(1, 4096, 4096, 3).contiguous()
+    planes = enc.convert(rgb).cpu().numpy()[0]
+    got = [hashlib.sha256(planes[i].tobytes()).hexdigest() for i in range(3)]
+    assert got == [want["Y"], want["Cb"], want["Cr"]]
+    enc.close()
+
+
+def test_colour_inside_fused_kernel_exhaustive(torch_cuda, orc):
+    """The fused strip kernel converts pixels itself; check its conversion on all 2^24 triples through
+    the DC coefficient path: a flat 8x8 block of colour c has every pixel equal, so compare full
+    coefficient sets of a picture made of flat 16x16 macroblocks with the oracle (8 pictures of 2048^2 / 256)."""
+    torch = torch_cuda
+    W = H = 2048  # 128 x 128 macroblocks = 16384 colours per picture; sample 64 pictures = 2^20 colours
+    enc = _enc(W, H, max_frames=1)
+    rng = np.random.default_rng(11)
+    for _ in range(4):
+        cols = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
+        pic = np.repeat(np.repeat(cols, 16, 0), 16, 1)[None]
+        got = enc.coefficients(torch.from_numpy(pic).cuda()).cpu().numpy().astype(np.int32)[0]
+        assert np.array_equal(got, orc.frame_coefficients(pic[0], W, H, 12, orc.MODE_FULL))
+    enc.close()
+
+
+def test_subsample(torch_cuda, orc):
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    W, H = 352, 288
+    cb = rng.integers(0, 256, W * H, dtype=np.uint8)
+    cr = rng.integers(0, 256, W * H, dtype=np.uint8)
+    enc = _enc(W, H)
+    a, b = enc.subsample(torch.from_numpy(cb).cuda(), torch.from_numpy(cr).cuda())
+    wa, wb = orc.subsample(cb, cr, W, H)
+    assert np.array_equal(a.cpu().numpy(), wa) and np.array_equal(b.cpu().numpy(), wb)
+    enc.close()
+
+
+@pytest.mark.parametrize("W,H,mode", [(1920, 1080, "full"), (1920, 1080, "strict"), (352, 288, "full"),
+                                      (360, 250, "full"), (100, 150, "strict"), (3840, 2160, "full")])
+def test_config2_coefficients_bit_exact(torch_cuda, orc, W, H, mode):
+    """BASELINE config 2: DCT+quant+zigzag only, every block coefficient vs the oracle."""
+    enc = _enc(W, H, mode=mode, max_frames=1)
+    rgb = enc.synth(1, seed=2024)
+    got = enc.coefficients(rgb).cpu().numpy().astype(np.int32)[0]
+    want = orc.frame_coefficients(rgb.cpu().numpy()[0], W, H, 12, _omode(orc, mode))
+    assert got.shape == want.shape and np.array_equal(got, want)
+    enc.close()
+
+
+@pytest.mark.parametrize("fn", G.E2E_FILES)
+def test_golden_files_through_hip(torch_cuda, orc, fn):
+    """Committed reference outputs (tests/golden, produced by the real reference): the HIP path must
+    reproduce the reference's .mpeg bytes from the stb-decoded pixels."""
+    torch = torch_cuda
+    z = G.load(fn)
+    rgb = z["rgb"]
+    n, H, W, C = rgb.shape
+    d = torch.from_numpy(rgb).cuda()
+    from ec504_imageencoder_amd import file_prolog
+    for _, qf, mode, _, want in G.e2e_cases([fn]):
+        enc = _enc(W, H, qf, mode, channels=C, max_frames=n)
+        got, sizes = enc.encode_to_bytes(d, 0)
+        assert file_prolog() + got == want, (fn, qf, mode)
+        assert sum(sizes) == len(got)
+        # host-buffer entry point gives the same bytes
+        hgot, hsizes = enc.encode_host(rgb, 0)
+        assert hgot == got and hsizes == sizes
+        # .bit side file planes
+        planes = enc.convert(d).cpu().numpy()
+        for i in range(n):
+            blob = struct.pack("<ii", W, H) + planes[i].tobytes()
+            assert hashlib.sha256(blob).hexdigest() == str(z["bit_sha256"][i])
+        enc.close()
+
+
+def test_golden_300_frames_hour_wrap(torch_cuda, orc):
+    torch = torch_cuda
+    z = G.load("e2e_300_wrap.npz")
+    rgb = z["rgb"][z["frame_index"]]
+    n, H, W, C = rgb.shape
+    from ec504_imageencoder_amd import file_prolog
+    enc = _enc(W, H, 12, "strict", channels=C, max_frames=n)
+    got, _ = enc.encode_to_bytes(torch.from_numpy(rgb).cuda(), 0)
+    assert file_prolog() + got == z["mpeg_strict_q12"].tobytes()
+    # two batches with the right global index give the same stream (sharding invariant)
+    a, _ = enc.encode_to_bytes(torch.from_numpy(rgb[:130]).cuda(), 0)
+    b, _ = enc.encode_to_bytes(torch.from_numpy(rgb[130:]).cuda(), 130)
+    assert a + b == got
+    enc.close()
+
+
+@pytest.mark.parametrize("W,H,mode,qf,n", [(352, 288, "full", 12, 4), (352, 288, "strict", 50, 3), (96, 144, "strict", 12, 2),
+                                           (1920, 1080, "full", 12, 3), (1920, 1080, "full", 30, 2), (400, 600, "full", 5, 2),
+                                           (360, 250, "full", 12, 2), (366, 250, "full", 12, 2), (100, 150, "strict", 12, 2),
+                                           (3840, 2160, "full", 12, 1), (32, 3008, "full", 12, 2), (16, 16, "full", 12, 9)])
+def test_random_frames_byte_exact(torch_cuda, orc, W, H, mode, qf, n):
+    """Seeded synthetic frames: HIP stream == oracle stream, sizes too.  Covers the unaligned-width
+    slow load path (366), tall strips that need the chunk loop (3008 rows = 1128 blocks per strip),
+    4K (strip byte 0xF0, dimension wrap) and the smallest picture."""
+    enc = _enc(W, H, qf, mode, max_frames=n)
+    rgb = enc.synth(n, seed=1234 + W)
+    got, sizes = enc.encode_to_bytes(rgb, first_frame_index=250)  # crosses the hour wrap at 256
+    want, wsizes = orc.encode_frames(rgb.cpu().numpy(), n, W, H, 250, qf, _omode(orc, mode), threads=8)
+    assert got == want
+    assert sizes == [int(s) for s in wsizes]
+    enc.close()
+
+
+def test_rgba_input(torch_cuda, orc):
+    W, H, n = 352, 288, 2
+    enc = _enc(W, H, 12, "full", channels=4, max_frames=n)
+    rgb = enc.synth(n, seed=9)
+    got, _ = enc.encode_to_bytes(rgb, 0)
+    want, _ = orc.encode_frames(rgb.cpu().numpy(), n, W, H, 0, 12, orc.MODE_FULL, channels=4)
+    assert got == want
+    enc.close()
+
+
+_ZIGZAG = np.array([0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24,
+                    31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56,
+                    59, 61, 35, 36, 48, 49, 57, 58, 62, 63])
+
+
+def _heavy_picture(rng, W, H, npos, amp, big_fraction=0.0):
+    """Grey picture whose every 8x8 block is an inverse DCT of `npos` ISOLATED coefficients (odd zigzag
+    positions, so each has run >= 1 and VLC_encode never stops early) of magnitude up to `amp`:
+    long code sequences, table codes and 20-bit escapes.  A `big_fraction` of the blocks instead carries
+    ONE coefficient of magnitude 400..500 at zigzag position 1 or 3 (level >= 128 at qf 92: 28-bit escape)."""
+    from scipy.fft import idctn
+    inv = np.argsort(_ZIGZAG)
+    pic = np.zeros((H, W, 3), np.uint8)
+    for by in range(0, H, 8):
+        for bx in range(0, W, 8):
+            c = np.zeros(64)
+            c[0] = 8 * 128
+            if rng.random() < big_fraction:
+                c[inv[rng.choice([1, 3])]] = rng.choice([-1, 1]) * rng.uniform(400, 500)
+            else:
+                pos = rng.choice(np.arange(1, 64, 2), size=npos, replace=False)
+                c[inv[pos]] = rng.choice([-1, 1], npos) * rng.uniform(amp * 0.5, amp, npos)
+            g = np.clip(np.round(idctn(c.reshape(8, 8), norm="ortho")), 0, 255).astype(np.uint8)
+            pic[by:by + 8, bx:bx + 8, :] = g[..., None]
+    return pic
+
+
+def _emitted_levels(z):
+    """AC levels VLC_encode actually codes: up to the first non-zero whose predecessor is non-zero."""
+    out = []
+    for p in range(1, 64):
+        if z[p] != 0:
+            if z[p - 1] != 0:
+                break
+            out.append(int(z[p]))
+    return out
+
+
+@pytest.mark.parametrize("qf,npos,amp,big", [(12, 6, 700, 0.0), (50, 8, 300, 0.0), (90, 16, 120, 0.0), (92, 10, 130, 0.4)])
+def test_long_blocks_and_global_fallback(torch_cuda, orc, qf, npos, amp, big):
+    """Blocks longer than 64 bits (register accumulator overflows -> second walk), 20- and 28-bit
+    escapes, and strips larger than the LDS image (forced with a tiny LDS capacity -> global-memory
+    atomics path) must still match the oracle bit for bit."""
+    torch = torch_cuda
+    rng = np.random.default_rng(qf * 100 + npos)
+    W, H = 176, 144
+    pics = []
+    for _ in range(6):
+        p = _heavy_picture(rng, W, H, npos, amp, big)
+        try:  # drop pictures the reference itself cannot encode (|level| >= 256 -> segfault)
+            orc.encode_frame(p, W, H, 0, qf, orc.MODE_FULL)
+            pics.append(p)
+        except ValueError:
+            pass
+    assert len(pics) >= 2
+    pics = np.stack(pics)
+    co = orc.frame_coefficients(pics[0], W, H, qf, orc.MODE_FULL)
+    assert max(len(orc.encode_block_bits(1, z)[1]) for z in co[:240]) > 64
+    if big:
+        assert any(abs(v) >= 128 for z in co for v in _emitted_levels(z))  # 28-bit escapes are exercised
+    if big:
+        assert any(40 < abs(v) < 128 for z in co for v in _emitted_levels(z))  # and 20-bit ones
+    want, wsizes = orc.encode_frames(pics, len(pics), W, H, 0, qf, orc.MODE_FULL)
+    for lds_words in (0, 64, 8):
+        enc = _enc(W, H, qf, "full", max_frames=len(pics))
+        enc.debug_set_lds_words(lds_words)
+        got, sizes = enc.encode_to_bytes(torch.from_numpy(pics).cuda(), 0)
+        assert got == want, (qf, lds_words)
+        assert sizes == [int(x) for x in wsizes]
+        enc.close()
+
+
+def test_unencodable_level_is_reported(torch_cuda, orc):
+    """|level| >= 256 with run >= 1: the reference dereferences NULL (vlc.c:349 -> bit_vector.c:100).
+    The HIP path reports M1V_E_UNENCODABLE instead of producing bytes; the oracle flags the same input."""
+    torch = torch_cuda
+    from ec504_imageencoder_amd import EncoderError, _ffi
+    W, H, qf = 96, 144, 92
+    yy, xx = np.mgrid[0:H, 0:W]
+    a = ((yy % 8) < 4).astype(np.uint8) * 255     # vertical step: zigzag position 2 = 308 after a zero at 1
+    pic = np.stack([a, a, a], -1)[None]
+    with pytest.raises(ValueError):
+        orc.encode_frame(pic[0], W, H, 0, qf, orc.MODE_FULL)
+    enc = _enc(W, H, qf, "full", max_frames=1)
+    with pytest.raises(EncoderError) as ei:
+        enc.encode_to_bytes(torch.from_numpy(pic).cuda(), 0)
+    assert ei.value.code == _ffi.E_UNENCODABLE
+    with pytest.raises(EncoderError) as ei:
+        enc.encode_host(pic, 0)
+    assert ei.value.code == _ffi.E_UNENCODABLE
+    enc.close()
+
+
+def test_argument_errors(torch_cuda):
+    from ec504_imageencoder_amd import EncoderError, Mpeg1Encoder
+    with pytest.raises(EncoderError):
+        Mpeg1Encoder(64, 64, 12, "strict")      # 96x144 region does not fit (reference reads out of bounds)
+    with pytest.raises(EncoderError):
+        Mpeg1Encoder(8, 8, 12, "full")          # not even one macroblock
+    with pytest.raises(EncoderError):
+        Mpeg1Encoder(352, 288, 12, "full", channels=2)
+    enc = Mpeg1Encoder(352, 288, 12, "full", max_frames=2)
+    rgb = enc.synth(3)
+    with pytest.raises(EncoderError):
+        enc.encode(rgb)                          # 3 frames > max_frames
+    enc.close()
+
+
+def test_output_capacity_is_checked(torch_cuda, orc):
+    torch = torch_cuda
+    from ec504_imageencoder_amd import _ffi
+    enc = _enc(352, 288, 12, "full", max_frames=2)
+    rgb = enc.synth(2)
+    small = torch.zeros(6000, dtype=torch.uint8, device="cuda")   # one frame fits, two do not
+    out, sizes, meta = enc.encode(rgb, 0, out=small)
+    torch.cuda.synchronize()
+    total, status = (int(x) for x in meta.cpu())
+    assert status & _ffi.STATUS_NOSPACE
+    want, wsizes = orc.encode_frames(rgb.cpu().numpy(), 2, 352, 288, 0, 12, orc.MODE_FULL)
+    assert total == len(want)                                      # sizes are still exact
+    assert small[:int(wsizes[0])].cpu().numpy().tobytes() == want[:int(wsizes[0])]
+    enc.close()
+
+
+def test_full_size_batch_properties(torch_cuda, orc):
+    """BASELINE config 3 at full size (300 x 1080p): properties that do not need 300 oracle frames —
+    (1) determinism, (2) every frame record parses (headers, back-patched length, trailer),
+    (3) a frame encoded alone with its global index equals its record inside the batch (sharding
+    invariant), (4) six frames spot-checked byte for byte against the oracle, (5) sum of sizes == total."""
+    torch = torch_cuda
+    W, H, n = 1920, 1080, 300
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    rgb = enc.synth(n, seed=504)
+    out, sizes, meta = enc.encode(rgb, 0)
+    out2, sizes2, meta2 = enc.encode(rgb, 0, out=torch.empty_like(out))
+    torch.cuda.synchronize()
+    total, status = (int(x) for x in meta.cpu())
+    assert status == 0 and total == int(meta2.cpu()[0])
+    assert torch.equal(out[:total], out2[:total]) and torch.equal(sizes, sizes2)
+    blob = out[:total].cpu().numpy().tobytes()
+    sz = [int(s) for s in sizes.cpu()]
+    assert sum(sz) == total
+    off = 0
+    for f in range(n):
+        rec = blob[off:off + sz[f]]
+        assert rec[:4] == b"\x00\x00\x01\xe0" and rec[16:20] == b"\x00\x00\x01\xb3"
+        assert rec[28:32] == b"\x00\x00\x01\xb8" and rec[36:44] == b"\x00\x00\x01\x00\x00\x0f\xff\xf8"
+        assert rec[32] == ((f & 0xFF) & 0x1F) << 2
+        assert struct.unpack(">H", rec[4:6])[0] == (sz[f] - 48 + 36) & 0xFFFF
+        assert rec[44:49] == b"\x00\x00\x01\x01\x0b" or rec[44:48] == b"\x00\x00\x01\x01"
+        assert rec[-4:] == b"\x00\x00\x00\x00"
+        off += sz[f]
+    offs = np.concatenate([[0], np.cumsum(sz)])
+    for f in (0, 1, 149, 255, 256, 299):
+        want = orc.encode_frame(rgb[f].cpu().numpy(), W, H, f, 12, orc.MODE_FULL)
+        assert blob[offs[f]:offs[f + 1]] == want, f
+        alone, _ = enc.encode_to_bytes(rgb[f:f + 1], first_frame_index=f)
+        assert alone == want
+    enc.close()

@@ -1,0 +1,33 @@
+"""Host-checkable arithmetic facts the kernels rely on."""
+import numpy as np
+
+
+def test_reciprocal_quantiser_is_exact():
+    """k_encode_strips quantises with one fp32 multiply by rq = fl((1/d)(1+2^-20)) and a truncating
+    convert.  Check trunc(n * rq) == trunc(n / d) (C division) for every divisor the scaled matrix can
+    hold (1..4150 = round(83*50)) and every |n| < 2^15 (FDCT outputs of u8 blocks stay below 2^13)."""
+    n = np.arange(0, 1 << 15, dtype=np.int32)
+    nf = n.astype(np.float32)
+    for d in range(1, 4151):
+        rq = np.float32((1.0 / d) * (1.0 + 1.0 / 1048576.0))
+        got = (nf * rq).astype(np.int32)          # fp32 multiply, truncation
+        assert np.array_equal(got, n // d), d
+        # negative side: fp32 multiply and C truncation are both sign-symmetric
+        assert np.array_equal((-nf * rq).astype(np.int32), -(n // d)), d
+
+
+def test_fdct_output_range(orc):
+    """|coefficient| < 2^13 for u8 input (needed by the int16 staging and the reciprocal quantiser)."""
+    rng = np.random.default_rng(0)
+    worst = 0
+    blocks = [np.full(64, 255, np.uint8), np.zeros(64, np.uint8)]
+    i, j = np.divmod(np.arange(64), 8)
+    for u in range(8):
+        for v in range(8):  # sign patterns of every basis function maximise that coefficient
+            pat = np.cos((2 * i + 1) * u * np.pi / 16) * np.cos((2 * j + 1) * v * np.pi / 16)
+            blocks.append(((pat > 0) * 255).astype(np.uint8))
+            blocks.append(((pat < 0) * 255).astype(np.uint8))
+    blocks += [rng.integers(0, 2, 64).astype(np.uint8) * 255 for _ in range(2000)]
+    for b in blocks:
+        worst = max(worst, int(np.abs(orc.fdct(b)).max()))
+    assert worst < (1 << 13), worst
