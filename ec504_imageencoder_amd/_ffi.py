@@ -19,9 +19,12 @@ _u8p = C.POINTER(C.c_uint8)
 MPEG1_HIP_SYMBOLS = [
     "m1v_device_count", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
     "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
-    "m1v_coefficients_device", "m1v_convert_device", "m1v_subsample_device", "m1v_synth_device",
+    "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words",
 ]
+
+
+ENCODER_H_SYMBOLS = ["mpeg_encode_procedure", "mpeg_encode_procedure_region", "encoder_set_image_loader"]
 
 
 class EncoderLibraryMissing(RuntimeError):
@@ -63,6 +66,8 @@ def lib():
     L.m1v_coefficients_device.restype = C.c_int
     L.m1v_convert_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.m1v_convert_device.restype = C.c_int
+    L.m1v_convert_host.argtypes = [vp, vp, C.c_int, vp]
+    L.m1v_convert_host.restype = C.c_int
     L.m1v_subsample_device.argtypes = [vp, vp, vp, vp, vp, vp]
     L.m1v_subsample_device.restype = C.c_int
     L.m1v_synth_device.argtypes = [vp, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64, vp]
@@ -73,9 +78,12 @@ def lib():
     L.m1v_profile_read.restype = C.c_int
     L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
     L.m1v_debug_set_lds_words.restype = C.c_int
-    if hasattr(L, "mpeg_encode_procedure"):
-        L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
-        L.mpeg_encode_procedure.restype = C.c_int
+    L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.mpeg_encode_procedure.restype = C.c_int
+    L.mpeg_encode_procedure_region.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.mpeg_encode_procedure_region.restype = C.c_int
+    L.encoder_set_image_loader.argtypes = [C.c_void_p, C.c_void_p]
+    L.encoder_set_image_loader.restype = None
     _lib = L
     return L
 

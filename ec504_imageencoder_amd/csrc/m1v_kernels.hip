@@ -1174,6 +1174,25 @@ int m1v_convert_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, uint8
     return M1V_OK;
 }
 
+int m1v_convert_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, uint8_t *planes) {
+    if (!e || !rgb || !planes || n_frames < 0) return fail(M1V_E_ARG, "bad argument%s");
+    if (n_frames == 0) return M1V_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    size_t in_bytes = (size_t)e->g.frame_bytes * n_frames;
+    size_t out_bytes = (size_t)e->g.W * e->g.H * 3 * n_frames;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    hipError_t err = hipMalloc(&d_in, in_bytes);
+    if (err == hipSuccess) err = hipMalloc(&d_out, out_bytes);
+    if (err == hipSuccess) err = hipMemcpy(d_in, rgb, in_bytes, hipMemcpyHostToDevice);
+    int rc = M1V_OK;
+    if (err == hipSuccess) rc = m1v_convert_device(e, d_in, n_frames, d_out, nullptr);
+    if (err == hipSuccess && rc == M1V_OK) err = hipMemcpy(planes, d_out, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (err != hipSuccess) return fail(M1V_E_HIP, "HIP: %s", hipGetErrorString(err));
+    return rc;
+}
+
 int m1v_subsample_device(m1v_encoder *e, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_cb_sub,
                          uint8_t *d_cr_sub, void *stream) {
     if (!e || !d_cb || !d_cr || !d_cb_sub || !d_cr_sub) return fail(M1V_E_ARG, "bad argument%s");

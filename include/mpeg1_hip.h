@@ -16,7 +16,7 @@
  *       the strip zero-padding (encoder.h:442), the 16-bit length back-patch (encoder.h:448-453)
  *       and the 4 trailing bytes (encoder.h:456-458).
  *   m1v_coefficients_device    fast_DCT + quantization + zigzag_scanning only (BASELINE config 2)
- *   m1v_convert_device         convert_rgb_to_ycbcr, image_processing.c:68-110 (feeds the .bit files,
+ *   m1v_convert_device/_host   convert_rgb_to_ycbcr, image_processing.c:68-110 (feeds the .bit files,
  *                              write_to_bitstream image_processing.c:753)
  *   m1v_subsample_device       subsampling_420, image_processing.c:114-133 (dead in the reference's
  *                              data flow; provided for completeness)
@@ -99,6 +99,8 @@ int m1v_coefficients_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames
 /* Full-resolution planes per frame: Y[w*h] Cb[w*h] Cr[w*h] (3*w*h bytes per frame). */
 int m1v_convert_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, uint8_t *d_planes,
                        void *stream);
+/* Host-buffer form of m1v_convert_device (synchronous; feeds the image_<k>.bit side files). */
+int m1v_convert_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, uint8_t *planes);
 /* 2x2 truncated mean of one Cb and one Cr plane (even width and height). */
 int m1v_subsample_device(m1v_encoder *enc, const uint8_t *d_cb, const uint8_t *d_cr,
                          uint8_t *d_cb_sub, uint8_t *d_cr_sub, void *stream);

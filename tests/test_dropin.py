@@ -1,0 +1,110 @@
+"""Drop-in boundary: the reference's OWN main.c, unmodified, compiled where it lies against
+include/encoder.h and linked to libencoder.so (`make dropin`), behaves like the reference's ./encoder:
+same return codes and side effects on the error paths (CPU, here) and byte-identical .mpeg/.bit
+output end to end (GPU box, with the prebuilt binaries that travel in build/ and oracle/_ref/)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "build", "dropin_encoder")
+CLI = os.path.join(ROOT, "encoder")
+REF_STRICT = os.path.join(ROOT, "oracle", "_ref", "ref_encoder_strict")
+REF_FULL = os.path.join(ROOT, "oracle", "_ref", "ref_encoder_full")
+
+
+@pytest.fixture(scope="module")
+def dropin():
+    if os.path.exists("/root/reference/main.c"):
+        subprocess.run(["make", "-s", "-C", ROOT, "dropin", "encoder"], check=True, stdout=subprocess.DEVNULL)
+    if not os.path.exists(DROPIN):
+        pytest.skip("build/dropin_encoder not built (reference main.c absent)")
+    return DROPIN
+
+
+def _run(exe, cwd, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([exe, *args], cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=e).returncode
+
+
+def _jpegs(folder, frames, quality=95):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    for i, a in enumerate(frames):
+        Image.fromarray(a).save(os.path.join(folder, f"f{i:03d}.jpg"), quality=quality)
+
+
+@pytest.mark.reference
+def test_unmodified_main_links_against_two_symbols(dropin):
+    out = subprocess.run(["nm", "-u", dropin], capture_output=True, text=True).stdout
+    ours = sorted(l.split()[-1] for l in out.splitlines() if "GLIBC" not in l and " U " in l)
+    assert ours == ["encoder_set_image_loader", "mpeg_encode_procedure"]
+
+
+@pytest.mark.reference
+def test_error_conventions_match_reference(dropin, ref, tmp_path):
+    """Return codes and file side effects on the paths that end before any frame is encoded
+    (encoder.h:75-80, 104-116, 119-124, 175-183) — identical to the real reference binary."""
+    def both(setup):
+        res = []
+        for name, exe, args in (("ours", dropin, []), ("ref", REF_STRICT, ["images/", "bitstreams", "bitstreams/awesome_video.mpeg", "12"])):
+            d = tmp_path / f"{setup.__name__}_{name}"
+            d.mkdir()
+            setup(d)
+            rc = _run(exe, str(d), *args)
+            video = d / "bitstreams" / "awesome_video.mpeg"
+            res.append((rc, video.read_bytes() if video.exists() else None, sorted(os.listdir(d))))
+        return res
+
+    def no_bitstreams_dir(d):
+        (d / "images").mkdir()
+    def no_images_dir(d):
+        (d / "bitstreams").mkdir()
+    def empty_images_dir(d):
+        (d / "bitstreams").mkdir(); (d / "images").mkdir()
+    def mismatched_dimensions(d):
+        (d / "bitstreams").mkdir()
+        rng = np.random.default_rng(0)
+        _jpegs(str(d / "images"), [rng.integers(0, 256, (144, 96, 3), dtype=np.uint8), rng.integers(0, 256, (160, 96, 3), dtype=np.uint8)])
+    def not_a_jpeg(d):
+        (d / "bitstreams").mkdir(); (d / "images").mkdir()
+        (d / "images" / "broken.jpg").write_bytes(b"this is not a jpeg")
+
+    for setup, want_rc in ((no_bitstreams_dir, 1), (no_images_dir, 0), (empty_images_dir, 255), (mismatched_dimensions, 255), (not_a_jpeg, 255)):
+        ours, theirs = both(setup)
+        assert ours[0] == theirs[0] == want_rc, setup.__name__
+        assert ours[1] == theirs[1], setup.__name__         # 27-byte prolog or no file at all
+        assert ours[2] == theirs[2], setup.__name__         # same directories created
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("region", ["strict", "full"])
+def test_cli_end_to_end_vs_reference_binary(region, tmp_path):
+    """BASELINE config 0: 4 x CIF random-pixel JPEGs through the unmodified main.c + libencoder.so (HIP)
+    vs the real reference ./encoder on the same folder: byte-identical .mpeg and image_<k>.bit."""
+    ref_exe = REF_STRICT if region == "strict" else REF_FULL
+    if not (os.path.exists(DROPIN) and os.path.exists(ref_exe)):
+        pytest.skip("prebuilt drop-in / reference binaries not shipped")
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(352)
+    frames = [rng.integers(0, 256, (288, 352, 3), dtype=np.uint8) for _ in range(4)]
+    d = tmp_path
+    _jpegs(str(d / "images"), frames)
+    (d / "bitstreams").mkdir()
+    (d / "ref_bits").mkdir()
+    assert _run(DROPIN, str(d), env={"EC504_ENCODE_REGION": region}) == 0
+    assert _run(ref_exe, str(d), "images/", "ref_bits", "ref_bits/awesome_video.mpeg", "12") == 0
+    ours = (d / "bitstreams" / "awesome_video.mpeg").read_bytes()
+    theirs = (d / "ref_bits" / "awesome_video.mpeg").read_bytes()
+    assert len(ours) > 1000 and ours == theirs
+    for k in range(1, 5):
+        assert (d / "bitstreams" / f"image_{k}.bit").read_bytes() == (d / "ref_bits" / f"image_{k}.bit").read_bytes()
+    # our own CLI (tools/encoder_cli.c) with explicit arguments gives the same file
+    if os.path.exists(CLI):
+        (d / "cli_bits").mkdir()
+        assert _run(CLI, str(d), "images/", "cli_bits", "cli_bits/v.mpeg", "12", region, env={"EC504_WRITE_BIT": "0"}) == 0
+        assert (d / "cli_bits" / "v.mpeg").read_bytes() == theirs
+        assert not (d / "cli_bits" / "image_1.bit").exists()
