@@ -53,6 +53,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ec504_imageencoder_amd import Mpeg1Encoder
+    from ec504_imageencoder_amd.sharding import gather_bitstreams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,23 +81,11 @@ def main():
         nonlocal gathered
         enc.encode(rgb, first, out=out, sizes=sizes, meta=meta)
         if distributed:
-            # the path's one exchange: per-rank byte counts, then the blobs to rank 0 (xGMI)
-            totals = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(totals, meta[:1])
-            t = [int(x) for x in totals.cpu()]
+            # the path's one exchange: per-rank byte counts, then the blobs to rank 0 over xGMI
+            total = int(meta[0].item())
+            res, _ = gather_bitstreams(out, total, dst=gathered)
             if rank == 0:
-                if gathered is None or gathered.numel() < sum(t):
-                    gathered = torch.empty(int(sum(t) * 1.05) + 4096, dtype=torch.uint8, device=dev)
-                gathered[:t[0]].copy_(out[:t[0]])
-                ops, off = [], t[0]
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, gathered[off:off + t[r]], r))
-                    off += t[r]
-                for w_ in dist.batch_isend_irecv(ops):
-                    w_.wait()
-            else:
-                for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, out[:t[rank]], 0)]):
-                    w_.wait()
+                gathered = res if gathered is None or gathered.numel() < res.numel() else gathered
 
     def fence():
         if distributed:
