@@ -45,6 +45,7 @@ constexpr int kMaxThreads = 1024;
 constexpr int kAcRows = 32, kAcCols = 40;         // AC lookup: [run-1][|level|-1]
 constexpr int kLutWords = kAcRows * kAcCols;      // 1280
 constexpr int kDcWords = 32;                      // 2 x 9 used
+constexpr int kSlotWords = 16;                    // stage_slot table, 64 bytes
 constexpr int kMaxBlockBits = 886;
 constexpr int kDefaultLdsWords = 4096;            // 16 KiB strip image in LDS
 
@@ -63,11 +64,20 @@ __host__ __device__ constexpr int scan_inv(int p) {
     return -1;
 }
 
+// LDS staging of one lane's 64 levels: word row (u/2)*8 + i holds dct_block[u][i] (u even: low half,
+// u odd: high half), so a column's results can be stored as soon as that column is done.
+// stage_slot(p) = word_row*2 + half for zigzag position p.
+__host__ __device__ constexpr int stage_slot(int p) {
+    int k = scan_inv(p), u = k >> 3, i = k & 7;
+    return ((u >> 1) * 8 + i) * 2 + (u & 1);
+}
+
 // Device-resident tables, built by m1v_create.
 struct Tables {
     float rq[64];               // inflated reciprocal of the scaled quantiser, natural order
     uint32_t ac[kLutWords];     // (bits << 16) | code, 0 = escape.  [r][idx] with the reference's indexing
     uint32_t dc[kDcWords];      // [0..8] luma size codes, [16..24] chroma size codes
+    uint32_t slot[16];          // stage_slot(p) for p = 0..63, one byte each
     uint8_t hdr[256][44];       // PKT SEQ GOP PIC for hour = 0..255, length field zero
 };
 
@@ -79,6 +89,25 @@ struct Geometry {
     unsigned long long frame_bytes;
 };
 
+#ifdef M1V_STAMPS
+// Diagnostic build only (tools/stamps.py): per-phase cycle sums, lane 0 of every wave adds the cycles it
+// spent between two stamps into stamps[phase].  Never compiled into the shipped library.
+#define STAMP(ph)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();                                    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.stamps[ph], now_ - stamp_t_);                    \
+        stamp_t_ = __builtin_amdgcn_s_memtime();                                                   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define STAMP_INIT() unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define STAMP(ph) do { } while (0)
+#define STAMP_INIT() do { } while (0)
+#endif
+
 struct EncodeArgs {
     Geometry g;
     const uint8_t *rgb;
@@ -89,6 +118,7 @@ struct EncodeArgs {
     int n_frames;
     int threads;                // workgroup size
     int lds_words;              // capacity of the LDS strip image
+    unsigned long long *stamps; // diagnostic builds only
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -121,30 +151,70 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
     return c;
 }
 
+// fp32 coefficients of the same three formulas, for the fast path below
+struct CompCoefF {
+    float k0, kr, kg, kb;
+    int comp;
+};
+__device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
+    CompCoefF c;
+    c.k0 = comp == 0 ? 0.0f : 128.0f;
+    c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
+    c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
+    c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
+    c.comp = comp;
+    return c;
+}
+
+// Same value as component_fp64 for every (r,g,b), at fp32 cost.
+// The exact rational value x of a formula is a multiple of 1e-6 in [0.5, 255.5].  Three fp32 FMAs
+// give t with |t - x| <= 5e-5 (three half-ulps of 2^-16 plus three coefficient roundings of
+// 150 * 2^-24); the reference's fp64 result differs from x by < 1e-12.  So whenever t is farther than
+// 1e-4 from an integer, trunc(t) == trunc(fp64 result).  Otherwise (x is, or is within 1.5e-4 of, an
+// integer: ~0.1 % of pixels, exactly the cases where fp64 rounding decides the byte) the lane
+// re-evaluates the reference's fp64 expression.  tests: all 2^24 triples x 3 components on the GPU.
+__device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
+    float t = fmaf((float)b, k.kb, k.k0);
+    t = fmaf((float)g, k.kg, t);
+    t = fmaf((float)r, k.kr, t);
+    int q = (int)t;
+    float fr = __builtin_amdgcn_fractf(t);
+    if (!(fabsf(fr - 0.5f) < 0.4999f)) {
+        CompCoef d = comp_coef(k.comp);
+        q = component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
+    }
+    return q;
+}
+
 struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
 
+// 8 pixels of one block row (24 bytes already in registers) -> 8 component values
+__device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k, int out[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t c[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            int byte = 3 * j + ch;
+            c[ch] = (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+        }
+        out[j] = component(c[0], c[1], c[2], k);
+    }
+}
+
 // 8 pixels of one block row -> 8 component values.  FAST: C == 3 and the row starts 4-byte aligned.
 template <bool FAST>
-__device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoef &k, int out[8]) {
+__device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, int out[8]) {
     if (FAST) {
         Row24 v = *reinterpret_cast<const Row24 *>(p);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int c[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                int byte = 3 * j + ch;
-                c[ch] = (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xff;
-            }
-            out[j] = component_fp64(c[0], c[1], c[2], k.k0, k.kr, k.kg, k.kb);
-        }
+        convert_row24(v, k, out);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint8_t *q = p + j * C;
-            out[j] = component_fp64(q[0], q[1], q[2], k.k0, k.kr, k.kg, k.kb);
+            out[j] = component(q[0], q[1], q[2], k);
         }
     }
 }
@@ -162,17 +232,19 @@ __device__ __forceinline__ void butterfly8(const int v0, const int v1, const int
     int a3 = v3 + v4, d3 = v3 - v4;
     int e0 = a0 + a3, e3 = a0 - a3;
     int e1 = a1 + a2, e2 = a1 - a2;
-    int m12 = c1 * (d1 + d2);
-    int f2 = (-s1 - c1) * d2 + m12;
-    int f1 = (s1 - c1) * d1 + m12;
-    int m03 = c3 * (d0 + d3);
-    int f3 = (-s3 - c3) * d3 + m03;
-    int f0 = (s3 - c3) * d0 + m03;
+    // Every multiplicand fits 24 bits for u8 pixels (row pass |operand| <= 2^21, column pass <= 2^15;
+    // worst-case interval bounds in DESIGN.md), so the full-rate 24-bit multiplier is exact here.
+    int m12 = __mul24(c1, d1 + d2);
+    int f2 = __mul24(-s1 - c1, d2) + m12;
+    int f1 = __mul24(s1 - c1, d1) + m12;
+    int m03 = __mul24(c3, d0 + d3);
+    int f3 = __mul24(-s3 - c3, d3) + m03;
+    int f0 = __mul24(s3 - c3, d0) + m03;
     t[0] = e0 + e1;                       // x6
     t[1] = e0 - e1;                       // x4
-    int m78 = r2c6 * (e2 + e3);
-    t[3] = (-r2s6 - r2c6) * e2 + m78;     // x7
-    t[2] = (r2s6 - r2c6) * e3 + m78;      // x8
+    int m78 = __mul24(r2c6, e2 + e3);
+    t[3] = __mul24(-r2s6 - r2c6, e2) + m78; // x7
+    t[2] = __mul24(r2s6 - r2c6, e3) + m78;  // x8
     int g5 = f0 + f2, g0 = f0 - f2;
     int g2 = f3 + f1, g3 = f3 - f1;
     t[4] = g2 - g5;
@@ -181,37 +253,49 @@ __device__ __forceinline__ void butterfly8(const int v0, const int v1, const int
     t[7] = g0;
 }
 
-// px[i*8+j] -> c[u*8+i] (dct_block[u][i]), in place semantics of the two passes
-__device__ __forceinline__ void fdct_block(const int px[64], int c[64]) {
+// Row pass of one row (image_processing.c:198-250): 8 pixels -> rows[i][0..7]
+__device__ __forceinline__ void fdct_row(const int p[8], int out[8]) {
     constexpr int r2 = 181;
+    int t[8];
+    butterfly8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], t);
+    out[0] = t[0];
+    out[4] = t[1];
+    out[2] = t[2] >> 10;
+    out[6] = t[3] >> 10;
+    out[7] = t[4] >> 10;
+    out[1] = t[5] >> 10;
+    out[3] = __mul24(t[6], r2) >> 17;
+    out[5] = __mul24(t[7], r2) >> 17;
+}
+
+// Column pass of one column (image_processing.c:253-305): rows[0..7][i] -> dct_block[0..7][i]
+__device__ __forceinline__ void fdct_col(const int r0, const int r1, const int r2_, const int r3,
+                                         const int r4, const int r5, const int r6, const int r7, int c[8]) {
+    constexpr int r2 = 181;
+    int t[8];
+    butterfly8(r0, r1, r2_, r3, r4, r5, r6, r7, t);
+    c[0] = (t[0] + 16) >> 3;
+    c[4] = (t[1] + 16) >> 3;
+    c[2] = (t[2] + 16384) >> 13;
+    c[6] = (t[3] + 16384) >> 13;
+    c[7] = (t[4] + 16384) >> 13;
+    c[1] = (t[5] + 16384) >> 13;
+    c[3] = (__mul24(t[6] >> 8, r2) + 8192) >> 12;
+    c[5] = (__mul24(t[7] >> 8, r2) + 8192) >> 12;
+}
+
+// px[i*8+j] -> c[u*8+i] (dct_block[u][i])
+__device__ __forceinline__ void fdct_block(const int px[64], int c[64]) {
     int rows[64];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { // image_processing.c:198-250
-        int t[8];
-        butterfly8(px[i * 8 + 0], px[i * 8 + 1], px[i * 8 + 2], px[i * 8 + 3], px[i * 8 + 4],
-                   px[i * 8 + 5], px[i * 8 + 6], px[i * 8 + 7], t);
-        rows[i * 8 + 0] = t[0];
-        rows[i * 8 + 4] = t[1];
-        rows[i * 8 + 2] = t[2] >> 10;
-        rows[i * 8 + 6] = t[3] >> 10;
-        rows[i * 8 + 7] = t[4] >> 10;
-        rows[i * 8 + 1] = t[5] >> 10;
-        rows[i * 8 + 3] = (t[6] * r2) >> 17;
-        rows[i * 8 + 5] = (t[7] * r2) >> 17;
-    }
+    for (int i = 0; i < 8; i++) fdct_row(&px[i * 8], &rows[i * 8]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { // image_processing.c:253-305
-        int t[8];
-        butterfly8(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i],
-                   rows[4 * 8 + i], rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], t);
-        c[0 * 8 + i] = (t[0] + 16) >> 3;
-        c[4 * 8 + i] = (t[1] + 16) >> 3;
-        c[2 * 8 + i] = (t[2] + 16384) >> 13;
-        c[6 * 8 + i] = (t[3] + 16384) >> 13;
-        c[7 * 8 + i] = (t[4] + 16384) >> 13;
-        c[1 * 8 + i] = (t[5] + 16384) >> 13;
-        c[3 * 8 + i] = ((t[6] >> 8) * r2 + 8192) >> 12;
-        c[5 * 8 + i] = ((t[7] >> 8) * r2 + 8192) >> 12;
+    for (int i = 0; i < 8; i++) {
+        int col[8];
+        fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], col);
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u * 8 + i] = col[u];
     }
 }
 
@@ -250,7 +334,7 @@ template <bool FAST>
 __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint8_t *frame,
                                                    const BlockSrc &s, const float *rq, int q[64]) {
     int px[64];
-    CompCoef k = comp_coef(s.comp);
+    CompCoefF k = comp_coef_f(s.comp);
 #pragma unroll
     for (int i = 0; i < 8; i++)
         load_row<FAST>(frame + (s.first + (long long)i * s.stride) * g.C, g.C, k, &px[i * 8]);
@@ -353,6 +437,48 @@ __device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t v, uint32_t *w
     return off;
 }
 
+// Inclusive prefix sum across the 64 lanes of a wave with DPP row shifts / row broadcasts (gfx9 family):
+// no index registers, 7 VALU adds.  row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+// inclusive prefix sum across the first 16 lanes only (one DPP row)
+__device__ __forceinline__ uint32_t row_scan_inclusive(uint32_t v) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xe, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xc, false);
+    return x;
+}
+
+// Same, with ONE barrier: every wave redoes the (<= 16 entry) scan of the wave totals itself.  `ws` must
+// hold 2 x 16 words; callers alternate `parity` so that a buffer is rewritten only after another barrier.
+__device__ __forceinline__ uint32_t block_scan_exclusive_1b(uint32_t v, uint32_t *ws, int parity, int nthreads,
+                                                            uint32_t &total) {
+    int lane = threadIdx.x & (kWave - 1);
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t incl = wave_scan_inclusive(v);
+    uint32_t *buf = ws + parity * 16;
+    if (lane == kWave - 1) buf[wave] = incl;
+    __syncthreads();
+    int nw = nthreads >> 6;
+    uint32_t s = lane < nw ? buf[lane] : 0;
+    uint32_t si = row_scan_inclusive(s);
+    uint32_t wave_off = (uint32_t)__builtin_amdgcn_readlane((int)(si - s), wave);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)si, nw - 1);
+    return wave_off + incl - v;
+}
+
 // XCD-aware (frame, strip) of a workgroup: consecutive workgroup ids round-robin over the 8 XCDs,
 // so give each XCD whole frames (its L2 then sees every 128-byte line of the frame once).
 __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_strips, int &frame,
@@ -370,7 +496,9 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
     }
 }
 
-template <bool FAST>
+// MULTI: strips with more blocks than the workgroup has lanes (pictures taller than 2720 rows) loop over
+// chunks of macroblocks; the common single-chunk case is compiled without the loop.
+template <bool FAST, bool MULTI>
 __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Geometry &g = a.g;
@@ -378,7 +506,8 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
     const int tid = threadIdx.x;
     uint32_t *ac_lut = lds;                        // kLutWords
     uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
-    uint32_t *wave_sums = dc_lut + kDcWords;       // 32
+    uint32_t *slot_lut = dc_lut + kDcWords;        // kSlotWords
+    uint32_t *wave_sums = slot_lut + kSlotWords;   // 32
     uint32_t *stage = wave_sums + 32;              // 32 x T   (two int16 levels per word)
     uint32_t *image = stage + 32 * T;              // a.lds_words
 
@@ -388,47 +517,109 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(
         a.scratch + ((unsigned long long)frame * g.n_strips + strip) * g.strip_cap);
 
-    for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
-    if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
-    for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
-    __syncthreads();
-
-    // slice header (mpeg1_blk.c:12-16): 00 00 01, strip+1 (uint8 wrap), quant_scale=1 in 5 bits, a 0 bit
-    if (tid == 0) {
-        image[0] = 0x00000100u | ((uint32_t)(strip + 1) & 0xffu);
-        image[1] = 0x08000000u; // 00001 0 followed by zeros
-    }
+    STAMP_INIT();
     uint32_t bit_cursor = 38;
     bool global_mode = false;   // strip image lives in the scratch slot instead of LDS
     bool ok = true;
 
     const int blocks_per_strip = g.n_mbrows * 6;
     const int chunk = (T / 6) * 6;
-    for (int base = 0; base < blocks_per_strip; base += chunk) {
+    int parity = 0;
+    int base = 0;
+    do {
         int bidx = base + tid;
         bool valid = tid < chunk && bidx < blocks_per_strip;
 
-        // ---- coefficients, staged in LDS by zigzag position (two per word) ----
+        // ---- table loads first, then every pixel load of this lane's block (8 rows x 24 B): the
+        //      in-order vmcnt then lets the tables be consumed while the pixels are still in flight ----
+        constexpr int kLutRegs = 3;
+        uint32_t lutv[kLutRegs];
+        const bool lut_in_regs = base == 0 && T * kLutRegs >= kLutWords;
+        if (lut_in_regs) {
+#pragma unroll
+            for (int j = 0; j < kLutRegs; j++) {
+                int idx = tid + j * T;
+                lutv[j] = idx < kLutWords ? a.tab->ac[idx] : 0u;
+            }
+        }
+        BlockSrc src;
+        Row24 raw[8];
+        if (valid) {
+            src = block_source(g, strip, bidx);
+            if (FAST) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    raw[i] = *reinterpret_cast<const Row24 *>(fbase + (src.first + (long long)i * src.stride) * 3);
+            }
+        }
+
+        // ---- workgroup prologue, under the latency of those loads ----
+        if (base == 0) {
+            if (lut_in_regs) {
+#pragma unroll
+                for (int j = 0; j < kLutRegs; j++) {
+                    int idx = tid + j * T;
+                    if (idx < kLutWords) ac_lut[idx] = lutv[j];
+                }
+            } else {
+                for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
+            }
+            if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
+            if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = a.tab->slot[tid - 32];
+            for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
+            __syncthreads();
+            // slice header (mpeg1_blk.c:12-16): 00 00 01, strip+1 (uint8 wrap), quant_scale=1 in 5 bits, a 0 bit
+            if (tid == 0) {
+                image[0] = 0x00000100u | ((uint32_t)(strip + 1) & 0xffu);
+                image[1] = 0x08000000u; // 00001 0 followed by zeros
+            }
+        }
+        STAMP(0);
+
+        // ---- rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise +
+        //      stage in LDS + non-zero mask, one column at a time (nothing but rows[] stays live) ----
         unsigned long long nz = 0;
         int dc = 0, blk = 0, comp = 0;
         if (valid) {
-            BlockSrc s = block_source(g, strip, bidx);
-            blk = s.blk;
-            comp = s.comp;
-            int q[64];
-            block_coefficients<FAST>(g, fbase, s, a.tab->rq, q);
-            dc = q[0];
+            blk = src.blk;
+            comp = src.comp;
+            int rows[64];
+            {
+                CompCoefF k = comp_coef_f(src.comp);
 #pragma unroll
-            for (int m = 0; m < 32; m++) {
-                int lo = q[scan_inv(2 * m)], hi = q[scan_inv(2 * m + 1)];
-                stage[m * T + tid] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
-                if (lo != 0) nz |= 1ull << (2 * m);
-                if (hi != 0) nz |= 1ull << (2 * m + 1);
+                for (int i = 0; i < 8; i++) {
+                    int px[8];
+                    if (FAST)
+                        convert_row24(raw[i], k, px);
+                    else
+                        load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
+                    fdct_row(px, &rows[i * 8]);
+                }
             }
+            STAMP(1);
+            const float *rq = a.tab->rq;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int c[8], q[8];
+                fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                         rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    q[u] = quant(c[u], rq[u * 8 + i]);
+                    if (q[u] != 0) nz |= 1ull << scan_pos(u * 8 + i);
+                }
+                if (i == 0) dc = q[0];
+#pragma unroll
+                for (int h = 0; h < 4; h++)
+                    stage[(h * 8 + i) * T + tid] = ((uint32_t)q[2 * h] & 0xffffu) | ((uint32_t)q[2 * h + 1] << 16);
+            }
+            STAMP(2);
         }
+        STAMP(3);
         auto fetch = [&](int p) -> int {
-            uint32_t w = stage[(p >> 1) * T + tid];
-            return (p & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
+            uint32_t e = (slot_lut[p >> 2] >> ((p & 3) * 8)) & 0xffu;
+            uint32_t w = stage[(e >> 1) * T + tid];
+            return (e & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
         };
 
         // ---- DC part + macroblock header ----
@@ -475,8 +666,11 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
             ok &= walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
         }
 
+        STAMP(4);
         uint32_t chunk_bits;
-        uint32_t off = block_scan_exclusive((uint32_t)tot, wave_sums, T, chunk_bits) + bit_cursor;
+        uint32_t off = block_scan_exclusive_1b((uint32_t)tot, wave_sums, parity, T, chunk_bits) + bit_cursor;
+        parity ^= 1;
+        STAMP(5);
         uint32_t end_bits = bit_cursor + chunk_bits;
 
         // ---- strip image too large for LDS: continue in the (zeroed) scratch slot ----
@@ -528,8 +722,11 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
             }
         }
         bit_cursor = end_bits;
+        STAMP(6);
         __syncthreads(); // stage[] is reused by the next chunk; image writes complete
-    }
+        STAMP(7);
+        base += chunk;
+    } while (MULTI && base < blocks_per_strip);
 
     // ---- store the strip (zero bits pad it to a byte, encoder.h:442-443) ----
     uint32_t nbytes = (bit_cursor + 7) >> 3;
@@ -539,6 +736,7 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
     }
     if (tid == 0) a.strip_bytes[(unsigned long long)frame * g.n_strips + strip] = nbytes;
     if (!ok) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+    STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,12 +878,11 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *rgb, int C, unsi
     for (; i < total; i += (unsigned long long)gridDim.x * 256) {
         unsigned long long f = i / npx_frame, p = i - f * npx_frame;
         const uint8_t *q = rgb + i * C;
-        int r = q[0], gg = q[1], b = q[2];
+        uint32_t r = q[0], gg = q[1], b = q[2];
         uint8_t *o = planes + f * 3 * npx_frame;
-        CompCoef ky = comp_coef(0), kb = comp_coef(1), kr = comp_coef(2);
-        o[p] = (uint8_t)component_fp64(r, gg, b, ky.k0, ky.kr, ky.kg, ky.kb);
-        o[npx_frame + p] = (uint8_t)component_fp64(r, gg, b, kb.k0, kb.kr, kb.kg, kb.kb);
-        o[2 * npx_frame + p] = (uint8_t)component_fp64(r, gg, b, kr.k0, kr.kr, kr.kg, kr.kb);
+        o[p] = (uint8_t)component(r, gg, b, comp_coef_f(0));
+        o[npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(1));
+        o[2 * npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(2));
     }
 }
 
@@ -849,6 +1046,7 @@ struct m1v_encoder {
     uint32_t *d_strip_bytes, *d_strip_off;
     unsigned long long *d_frame_size, *d_frame_off;
     uint32_t *d_status;
+    unsigned long long *d_stamps;
     // profiling
     bool prof;
     std::vector<hipEvent_t> ev;
@@ -913,6 +1111,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->fast_ok = channels == 3 && (width % 8) == 0;
     e->prof = false;
     e->ev_used = 0;
+    e->d_stamps = nullptr;
 
     Tables *t = new Tables();
     int q[64];
@@ -920,6 +1119,11 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     for (int k = 0; k < 64; k++) t->rq[k] = (float)((1.0 / q[k]) * (1.0 + 1.0 / 1048576.0));
     build_ac_lut(t->ac);
     build_dc_lut(t->dc);
+    for (int w = 0; w < 16; w++) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) v |= (uint32_t)stage_slot(4 * w + b) << (8 * b);
+        t->slot[w] = v;
+    }
     for (int h = 0; h < 256; h++) build_frame_header(t->hdr[h], width, height, h);
 
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
@@ -932,12 +1136,22 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = hipMalloc(&e->d_frame_size, (size_t)max_frames * 8);
     if (err == hipSuccess) err = hipMalloc(&e->d_frame_off, (size_t)max_frames * 8);
     if (err == hipSuccess) err = hipMalloc(&e->d_status, sizeof(uint32_t));
+#ifdef M1V_STAMPS
+    if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 16 * 8);
+    if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
+#endif
     // strips of tall pictures need more than the default 64 KiB of dynamic LDS
     if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<true>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<false>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) {
         fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
@@ -959,6 +1173,7 @@ void m1v_destroy(m1v_encoder *e) {
     (void)hipFree(e->d_frame_size);
     (void)hipFree(e->d_frame_off);
     (void)hipFree(e->d_status);
+    (void)hipFree(e->d_stamps);
     delete e;
 }
 
@@ -978,6 +1193,17 @@ int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (e->lds_words < 4) e->lds_words = 4;
     return M1V_OK;
 }
+
+#ifdef M1V_STAMPS
+// diagnostic build only: read and clear the per-phase cycle sums
+int m1v_debug_read_stamps(m1v_encoder *e, unsigned long long out[16]) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->d_stamps, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->d_stamps, 0, 16 * 8));
+    return M1V_OK;
+}
+#endif
 
 int m1v_profile_enable(m1v_encoder *e, int enable) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
@@ -1042,14 +1268,21 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     a.n_frames = n_frames;
     a.threads = e->threads;
     a.lds_words = e->lds_words;
-    size_t lds = (size_t)(kLutWords + kDcWords + 32 + 32 * e->threads + e->lds_words) * 4;
+    a.stamps = e->d_stamps;
+    size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + 32 * e->threads + e->lds_words) * 4;
     if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
     dim3 grid((unsigned)((size_t)n_frames * g.n_strips)), block((unsigned)e->threads);
     if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
-    if (fast_path(e, d_rgb))
-        hipLaunchKernelGGL(k_encode_strips<true>, grid, block, lds, st, a);
+    const bool multi = g.n_mbrows * 6 > (e->threads / 6) * 6;
+    const bool fast = fast_path(e, d_rgb);
+    if (fast && !multi)
+        hipLaunchKernelGGL((k_encode_strips<true, false>), grid, block, lds, st, a);
+    else if (!fast && !multi)
+        hipLaunchKernelGGL((k_encode_strips<false, false>), grid, block, lds, st, a);
+    else if (fast)
+        hipLaunchKernelGGL((k_encode_strips<true, true>), grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL(k_encode_strips<false>, grid, block, lds, st, a);
+        hipLaunchKernelGGL((k_encode_strips<false, true>), grid, block, lds, st, a);
     if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
     HIP_TRY(hipGetLastError());
 

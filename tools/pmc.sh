@@ -1,0 +1,25 @@
+#!/bin/bash
+# PMC passes over bench.py (one rocprofv3 run per counter group; --pmc never combined with sys/hip traces).
+# usage (on the GPU box): bash tools/pmc.sh <tag> [bench args]
+set -u
+TAG=${1:-pmc}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+while read -r group; do
+  [ -z "$group" ] && continue
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $group --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- \
+      python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+done <<GROUPS
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE
+FETCH_SIZE
+WRITE_SIZE
+TCC_HIT_sum TCC_MISS_sum
+GROUPS
+python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
