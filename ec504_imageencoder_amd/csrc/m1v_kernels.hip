@@ -74,7 +74,8 @@ __host__ __device__ constexpr int stage_slot(int p) {
 
 // Device-resident tables, built by m1v_create.
 struct Tables {
-    float rq[64];               // inflated reciprocal of the scaled quantiser, natural order
+    float rq[64];               // inflated reciprocal of the scaled quantiser, natural order [u][i]
+    float rq_t[64];             // the same, transposed [i][u]: one 32-byte scalar load per column pass
     uint32_t ac[kLutWords];     // (bits << 16) | code, 0 = escape.  [r][idx] with the reference's indexing
     uint32_t dc[kDcWords];      // [0..8] luma size codes, [16..24] chroma size codes
     uint32_t slot[16];          // stage_slot(p) for p = 0..63, one byte each
@@ -103,6 +104,10 @@ struct Geometry {
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
 #define STAMP_INIT() unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#elif defined(M1V_MARKS)
+// Analysis build only (tools/isa_phases.py): comment markers in the .s between phases.
+#define STAMP(ph) asm volatile("; PHASE_MARK " #ph ::: "memory")
+#define STAMP_INIT() asm volatile("; PHASE_MARK start" ::: "memory")
 #else
 #define STAMP(ph) do { } while (0)
 #define STAMP_INIT() do { } while (0)
@@ -151,39 +156,92 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
     return c;
 }
 
-// fp32 coefficients of the same three formulas, for the fast path below
+// The rare exact path as a real (non-inlined) function: keeps ~20 fp64 instructions x 64 pixels and eight
+// per-lane fp64 constants out of the hot instruction stream.  rgb = r | g << 8 | b << 16.
+#ifndef M1V_SLOW_CALL
+#define M1V_SLOW_CALL 1
+#endif
+__device__ __attribute__((noinline)) int component_exact_call(uint32_t rgb, int comp) {
+    CompCoef d = comp_coef(comp);
+    return component_fp64((int)(rgb & 0xffu), (int)((rgb >> 8) & 0xffu), (int)((rgb >> 16) & 0xffu), d.k0, d.kr, d.kg,
+                          d.kb);
+}
+
+// fp32 coefficients of the same three formulas, for the fast path below.  k0 carries -kEps.
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr float kEps = 1.5e-4f;
 struct CompCoefF {
-    float k0, kr, kg, kb;
+    float2v k0, kr, kg, kb; // both halves equal: operands of the packed (2 pixels per instruction) FMAs
     int comp;
 };
 __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     CompCoefF c;
-    c.k0 = comp == 0 ? 0.0f : 128.0f;
-    c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
-    c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
-    c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
+    float k0 = (comp == 0 ? 0.0f : 128.0f) - kEps;
+    float kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
+    float kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
+    float kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
+    c.k0 = float2v{k0, k0};
+    c.kr = float2v{kr, kr};
+    c.kg = float2v{kg, kg};
+    c.kb = float2v{kb, kb};
     c.comp = comp;
     return c;
 }
 
-// Same value as component_fp64 for every (r,g,b), at fp32 cost.
+// Same value as component_fp64 for every (r,g,b), at fp32 cost, two pixels at a time.
 // The exact rational value x of a formula is a multiple of 1e-6 in [0.5, 255.5].  Three fp32 FMAs
-// give t with |t - x| <= 5e-5 (three half-ulps of 2^-16 plus three coefficient roundings of
-// 150 * 2^-24); the reference's fp64 result differs from x by < 1e-12.  So whenever t is farther than
-// 1e-4 from an integer, trunc(t) == trunc(fp64 result).  Otherwise (x is, or is within 1.5e-4 of, an
-// integer: ~0.1 % of pixels, exactly the cases where fp64 rounding decides the byte) the lane
-// re-evaluates the reference's fp64 expression.  tests: all 2^24 triples x 3 components on the GPU.
+// starting from k0 - eps give t with |t - (x - eps)| <= d, d = 6e-5 (three half-ulps of 2^-16, three
+// coefficient roundings of 150 * 2^-24, the rounding of k0 - eps); the reference's fp64 result differs
+// from x by < 1e-12.  Let n = trunc(t), h = fract(t).  If h <= 1 - 2 eps then
+// x is in [n + eps - d, n + 1 - eps + d], i.e. at least 9e-5 inside (n, n+1), so trunc(fp64 result) == n.
+// Otherwise (x within 3.6e-4 of an integer: < 0.1 % of pixels, among them exactly the ties where fp64
+// rounding decides the byte) the lane re-evaluates the reference's fp64 expression.
+// tests: all 2^24 triples x 3 components on the GPU.
+// Tuning switches (tools/ab.py builds variants with -D...):
+//   M1V_COLOUR_PK    1: two pixels per v_pk_fma_f32;   0: scalar FMAs
+//   M1V_SLOW_PIN     1: opaque asm keeps the rare path's byte extraction inside its branch
+//   M1V_ROW_BRANCH   1: one "any pixel of this row uncertain?" branch per 8 pixels, per-pixel fix-ups inside
+#ifndef M1V_COLOUR_PK
+#define M1V_COLOUR_PK 0
+#endif
+#ifndef M1V_ROW_BRANCH
+#define M1V_ROW_BRANCH 1
+#endif
+#ifndef M1V_SLOW_PIN
+#define M1V_SLOW_PIN 0
+#endif
+
+// `slow(i)` must return the exact fp64 component of pixel i (0 or 1); it runs only in the rare branch.
+template <typename Slow>
+__device__ __forceinline__ void component2(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1,
+                                           uint32_t b1, const CompCoefF &k, int &q0, int &q1, Slow slow) {
+    constexpr float lim = 1.0f - 2.0f * kEps;
+#if M1V_COLOUR_PK
+    float2v t = __builtin_elementwise_fma(float2v{(float)b0, (float)b1}, k.kb, k.k0);
+    t = __builtin_elementwise_fma(float2v{(float)g0, (float)g1}, k.kg, t);
+    t = __builtin_elementwise_fma(float2v{(float)r0, (float)r1}, k.kr, t);
+    float t0 = t.x, t1 = t.y;
+#else
+    float t0 = fmaf((float)b0, k.kb.x, k.k0.x);
+    t0 = fmaf((float)g0, k.kg.x, t0);
+    t0 = fmaf((float)r0, k.kr.x, t0);
+    float t1 = fmaf((float)b1, k.kb.x, k.k0.x);
+    t1 = fmaf((float)g1, k.kg.x, t1);
+    t1 = fmaf((float)r1, k.kr.x, t1);
+#endif
+    q0 = (int)t0;
+    q1 = (int)t1;
+    float h0 = __builtin_amdgcn_fractf(t0), h1 = __builtin_amdgcn_fractf(t1);
+    if (!(h0 <= lim)) q0 = slow(0);
+    if (!(h1 <= lim)) q1 = slow(1);
+}
 __device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
-    float t = fmaf((float)b, k.kb, k.k0);
-    t = fmaf((float)g, k.kg, t);
-    t = fmaf((float)r, k.kr, t);
-    int q = (int)t;
-    float fr = __builtin_amdgcn_fractf(t);
-    if (!(fabsf(fr - 0.5f) < 0.4999f)) {
+    int q0, q1;
+    component2(r, g, b, r, g, b, k, q0, q1, [&](int) {
         CompCoef d = comp_coef(k.comp);
-        q = component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
-    }
-    return q;
+        return component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
+    });
+    return q0;
 }
 
 struct __attribute__((aligned(4))) Row24 {
@@ -192,16 +250,51 @@ struct __attribute__((aligned(4))) Row24 {
 
 // 8 pixels of one block row (24 bytes already in registers) -> 8 component values
 __device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k, int out[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t c[3];
+    auto chan = [&](int j, int ch) -> uint32_t {
+        int byte = 3 * j + ch;
+        return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+    };
+    auto slow_px = [&](int j) -> int {
+        uint32_t e[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             int byte = 3 * j + ch;
-            c[ch] = (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+            uint32_t w = v.d[byte >> 2];
+#if M1V_SLOW_PIN
+            asm volatile("" : "+v"(w));
+#endif
+            e[ch] = (w >> ((byte & 3) * 8)) & 0xffu;
         }
-        out[j] = component(c[0], c[1], c[2], k);
+#if M1V_SLOW_CALL
+        return component_exact_call(e[0] | (e[1] << 8) | (e[2] << 16), k.comp);
+#else
+        CompCoef d = comp_coef(k.comp);
+        return component_fp64((int)e[0], (int)e[1], (int)e[2], d.k0, d.kr, d.kg, d.kb);
+#endif
+    };
+#if M1V_ROW_BRANCH
+    constexpr float lim = 1.0f - 2.0f * kEps;
+    bool bad[8], any = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float t = fmaf((float)chan(j, 2), k.kb.x, k.k0.x);
+        t = fmaf((float)chan(j, 1), k.kg.x, t);
+        t = fmaf((float)chan(j, 0), k.kr.x, t);
+        out[j] = (int)t;
+        bad[j] = !(__builtin_amdgcn_fractf(t) <= lim);
+        any |= bad[j];
     }
+    if (any) { // rare for the wave (~35 % of rows), then only the flagged pixels redo the fp64 expression
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (bad[j]) out[j] = slow_px(j);
+    }
+#else
+#pragma unroll
+    for (int j = 0; j < 8; j += 2)
+        component2(chan(j, 0), chan(j, 1), chan(j, 2), chan(j + 1, 0), chan(j + 1, 1), chan(j + 1, 2), k, out[j],
+                   out[j + 1], [&](int which) { return slow_px(j + which); });
+#endif
 }
 
 // 8 pixels of one block row -> 8 component values.  FAST: C == 3 and the row starts 4-byte aligned.
@@ -498,8 +591,15 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
 
 // MULTI: strips with more blocks than the workgroup has lanes (pictures taller than 2720 rows) loop over
 // chunks of macroblocks; the common single-chunk case is compiled without the loop.
+#ifndef M1V_PACK_ROWS
+#define M1V_PACK_ROWS 0
+#endif
+#ifndef M1V_WAVES_PER_EU
+#define M1V_WAVES_PER_EU 5
+#endif
 template <bool FAST, bool MULTI>
-__global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
+__global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(M1V_WAVES_PER_EU, M1V_WAVES_PER_EU)))
+void k_encode_strips(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Geometry &g = a.g;
     const int T = a.threads;
@@ -583,7 +683,12 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
         if (valid) {
             blk = src.blk;
             comp = src.comp;
+#if M1V_PACK_ROWS
+            // row-pass results (|v| <= 3200) kept as int16 pairs: 32 registers instead of 64
+            uint32_t rp[32];
+#else
             int rows[64];
+#endif
             {
                 CompCoefF k = comp_coef_f(src.comp);
 #pragma unroll
@@ -593,19 +698,37 @@ __global__ __launch_bounds__(kMaxThreads) void k_encode_strips(EncodeArgs a) {
                         convert_row24(raw[i], k, px);
                     else
                         load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
+#if M1V_PACK_ROWS
+                    int r8[8];
+                    fdct_row(px, r8);
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        rp[i * 4 + cc] = ((uint32_t)r8[2 * cc] & 0xffffu) | ((uint32_t)r8[2 * cc + 1] << 16);
+#else
                     fdct_row(px, &rows[i * 8]);
+#endif
                 }
             }
             STAMP(1);
-            const float *rq = a.tab->rq;
+            const float *rq_t = a.tab->rq_t;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 int c[8], q[8];
+#if M1V_PACK_ROWS
+                int v[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    uint32_t w = rp[r * 4 + (i >> 1)];
+                    v[r] = (i & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
+                }
+                fdct_col(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], c);
+#else
                 fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
                          rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c);
+#endif
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    q[u] = quant(c[u], rq[u * 8 + i]);
+                    q[u] = quant(c[u], rq_t[i * 8 + u]);
                     if (q[u] != 0) nz |= 1ull << scan_pos(u * 8 + i);
                 }
                 if (i == 0) dc = q[0];
@@ -1117,6 +1240,8 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     int q[64];
     scaled_matrix(quality_factor, q);
     for (int k = 0; k < 64; k++) t->rq[k] = (float)((1.0 / q[k]) * (1.0 + 1.0 / 1048576.0));
+    for (int u = 0; u < 8; u++)
+        for (int i = 0; i < 8; i++) t->rq_t[i * 8 + u] = t->rq[u * 8 + i];
     build_ac_lut(t->ac);
     build_dc_lut(t->dc);
     for (int w = 0; w < 16; w++) {
