@@ -20,7 +20,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_device_count", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
     "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
-    "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words",
+    "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
     L.m1v_profile_read.restype = C.c_int
     L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
     L.m1v_debug_set_lds_words.restype = C.c_int
+    L.m1v_debug_set_dense_threads.argtypes = [vp, C.c_int]
+    L.m1v_debug_set_dense_threads.restype = C.c_int
     L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.mpeg_encode_procedure.restype = C.c_int
     L.mpeg_encode_procedure_region.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]

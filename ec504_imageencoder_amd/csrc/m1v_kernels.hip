@@ -47,7 +47,7 @@ constexpr int kLutWords = kAcRows * kAcCols;      // 1280
 constexpr int kDcWords = 32;                      // 2 x 9 used
 constexpr int kSlotWords = 16;                    // stage_slot table, 64 bytes
 constexpr int kMaxBlockBits = 886;
-constexpr int kDefaultLdsWords = 4096;            // 16 KiB strip image in LDS
+constexpr int kDefaultLdsWords = 4096;            // 16 KiB strip image in LDS (strip-per-workgroup kernel)
 
 // zigzag position of natural-order coefficient [u][i] (image_processing.c:28-37)
 __host__ __device__ constexpr int scan_pos(int k) {
@@ -79,6 +79,7 @@ struct Tables {
     uint32_t ac[kLutWords];     // (bits << 16) | code, 0 = escape.  [r][idx] with the reference's indexing
     uint32_t dc[kDcWords];      // [0..8] luma size codes, [16..24] chroma size codes
     uint32_t slot[16];          // stage_slot(p) for p = 0..63, one byte each
+    uint32_t slot8[16];         // stage_slot8(p), the narrow (one byte per level) staging
     uint8_t hdr[256][44];       // PKT SEQ GOP PIC for hour = 0..255, length field zero
 };
 
@@ -159,7 +160,7 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
 // The rare exact path as a real (non-inlined) function: keeps ~20 fp64 instructions x 64 pixels and eight
 // per-lane fp64 constants out of the hot instruction stream.  rgb = r | g << 8 | b << 16.
 #ifndef M1V_SLOW_CALL
-#define M1V_SLOW_CALL 1
+#define M1V_SLOW_CALL 0
 #endif
 __device__ __attribute__((noinline)) int component_exact_call(uint32_t rgb, int comp) {
     CompCoef d = comp_coef(comp);
@@ -589,20 +590,159 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
     }
 }
 
-// MULTI: strips with more blocks than the workgroup has lanes (pictures taller than 2720 rows) loop over
-// chunks of macroblocks; the common single-chunk case is compiled without the loop.
-#ifndef M1V_PACK_ROWS
-#define M1V_PACK_ROWS 0
-#endif
 #ifndef M1V_WAVES_PER_EU
 #define M1V_WAVES_PER_EU 5
 #endif
-template <bool FAST, bool MULTI>
-__global__ __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(M1V_WAVES_PER_EU, M1V_WAVES_PER_EU)))
-void k_encode_strips(EncodeArgs a) {
+
+// ---- pieces shared by the two encode kernels -----------------------------------------------------
+
+// LDS staging of one lane's levels, narrow form: one BYTE per level, four levels per word; word row
+// (u/4)*8 + i holds dct_block[u][i], byte u%4.  Exact whenever no AC level can reach +-128, which the
+// host decides from the quantiser alone (m1v_create: 128 * min AC divisor > the largest |AC coefficient|
+// the FDCT can produce from u8 pixels).  The DC level never goes through the staging (kept in a register).
+__host__ __device__ constexpr int stage_slot8(int p) {
+    int k = scan_inv(p), u = k >> 3, i = k & 7;
+    return ((u >> 2) * 8 + i) * 4 + (u & 3);
+}
+
+// Issue the 8 row loads (8 x 24 B) of one block.
+__device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        raw[i] = *reinterpret_cast<const Row24 *>(fbase + (src.first + (long long)i * src.stride) * 3);
+}
+
+// rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
+// non-zero mask, one column at a time (nothing but rows[] stays live).  Returns the DC level.
+template <bool FAST, bool STAGE8>
+__device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
+                                              const Row24 raw[8], const float *rq_t, uint32_t *stage, int T,
+                                              int tid, unsigned long long &nz) {
+    int rows[64];
+    CompCoefF k = comp_coef_f(src.comp);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int px[8];
+        if (FAST)
+            convert_row24(raw[i], k, px);
+        else
+            load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
+        fdct_row(px, &rows[i * 8]);
+    }
+    int dc = 0;
+    nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int c[8], q[8];
+        fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            q[u] = quant(c[u], rq_t[i * 8 + u]);
+            if (q[u] != 0) nz |= 1ull << scan_pos(u * 8 + i);
+        }
+        if (i == 0) dc = q[0];
+        if (STAGE8) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                stage[(h * 8 + i) * T + tid] = ((uint32_t)q[4 * h] & 0xffu) | (((uint32_t)q[4 * h + 1] & 0xffu) << 8) |
+                                               (((uint32_t)q[4 * h + 2] & 0xffu) << 16) | ((uint32_t)q[4 * h + 3] << 24);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+                stage[(h * 8 + i) * T + tid] = ((uint32_t)q[2 * h] & 0xffffu) | ((uint32_t)q[2 * h + 1] << 16);
+        }
+    }
+    return dc;
+}
+
+template <bool STAGE8>
+__device__ __forceinline__ int fetch_level(const uint32_t *slot_lut, const uint32_t *stage, int T, int tid, int p) {
+    uint32_t e = (slot_lut[p >> 2] >> ((p & 3) * 8)) & 0xffu;
+    if (STAGE8) {
+        uint32_t w = stage[(e >> 2) * T + tid];
+        return (int)(w << (24 - 8 * (e & 3))) >> 24;
+    } else {
+        uint32_t w = stage[(e >> 1) * T + tid];
+        return (e & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
+    }
+}
+
+// DC part of a block (mpeg1_blk.c:73-102) with the macroblock header "11" (mpeg1_blk.c:38-51) in front
+// for block 0 of a macroblock.
+__device__ __forceinline__ void dc_header(int dc, bool luma, int blk, const uint32_t *dc_lut, uint32_t &hdr,
+                                          int &hlen) {
+    if (dc != 0) {
+        int coe = dc < 0 ? -dc : dc;
+        int low = coe & 0xff;
+        int sz = low ? 32 - __builtin_clz((unsigned)low) : 1;
+        uint32_t e = dc_lut[(luma ? 0 : 16) + sz];
+        if (dc < 0) coe ^= 1 << (sz - 1);
+        hdr = ((e & 0xffffu) << sz) | ((uint32_t)coe & 0xffu & ((1u << sz) - 1u));
+        hlen = (int)(e >> 16) + sz;
+    } else { // "100" / "00"
+        hdr = luma ? 0x4u : 0x0u;
+        hlen = luma ? 3 : 2;
+    }
+    if (blk == 0) { // macroblock_address_increment "1" + type "1"
+        hdr |= 3u << hlen;
+        hlen += 2;
+    }
+}
+
+// AC positions VLC_encode codes: the non-zeros below the first position whose predecessor is non-zero too
+__device__ __forceinline__ unsigned long long emit_set(unsigned long long nz) {
+    unsigned long long stop = nz & (nz << 1);
+    unsigned long long below = stop ? ((stop & (~stop + 1)) - 1) : ~0ull;
+    return nz & ~1ull & below;
+}
+
+// One lane's block bits: the first 64 in a register (the common case is the whole block), the count always.
+struct BlockBits {
+    unsigned long long acc;
+    int nacc, tot;
+    bool spilled;
+};
+
+// OR a block's bits into a zeroed word image at bit offset `off` (LDS image: logical big-endian words;
+// global image: byte-swapped so that memory is already the byte stream).
+template <bool GLOBAL, typename Walk>
+__device__ __forceinline__ void put_block(uint32_t *img, uint32_t off, const BlockBits &b, Walk walk) {
+    if (!b.spilled) {
+        unsigned long long A = b.acc << (64 - b.nacc);
+        uint32_t w = off >> 5, sh = off & 31u;
+        uint32_t w0 = (uint32_t)(A >> (32 + sh));
+        uint32_t w1 = (uint32_t)(A >> sh);
+        uint32_t w2 = sh ? ((uint32_t)A << (32 - sh)) : 0u;
+        if (GLOBAL) {
+            w0 = __builtin_bswap32(w0);
+            w1 = __builtin_bswap32(w1);
+            w2 = __builtin_bswap32(w2);
+        }
+        if (w0) atomicOr(&img[w], w0);
+        if (w1) atomicOr(&img[w + 1], w1);
+        if (w2) atomicOr(&img[w + 2], w2);
+    } else {
+        uint32_t pos = off;
+        auto sink = [&](uint32_t code, int bits) {
+            or_code<GLOBAL>(img, pos, code, bits);
+            pos += bits;
+        };
+        walk(sink);
+    }
+}
+
+// slice header (mpeg1_blk.c:12-16): 00 00 01, strip+1 (uint8 wrap), quant_scale = 1 in 5 bits, a 0 bit: 38 bits
+__device__ __forceinline__ uint32_t slice_word0(int strip) { return 0x00000100u | ((uint32_t)(strip + 1) & 0xffu); }
+constexpr uint32_t kSliceWord1 = 0x08000000u;
+
+// ---- kernel 1: one workgroup per strip (pictures with fewer than 64 blocks per strip, e.g. the
+//      reference's 96x144 region: 54 blocks) ---------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const Geometry &g = a.g;
-    const int T = a.threads;
+    const int T = a.threads; // == 64
     const int tid = threadIdx.x;
     uint32_t *ac_lut = lds;                        // kLutWords
     uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
@@ -617,247 +757,256 @@ void k_encode_strips(EncodeArgs a) {
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(
         a.scratch + ((unsigned long long)frame * g.n_strips + strip) * g.strip_cap);
 
-    STAMP_INIT();
-    uint32_t bit_cursor = 38;
-    bool global_mode = false;   // strip image lives in the scratch slot instead of LDS
-    bool ok = true;
-
     const int blocks_per_strip = g.n_mbrows * 6;
-    const int chunk = (T / 6) * 6;
-    int parity = 0;
-    int base = 0;
-    do {
-        int bidx = base + tid;
-        bool valid = tid < chunk && bidx < blocks_per_strip;
+    const bool valid = tid < blocks_per_strip;
+    BlockSrc src;
+    Row24 raw[8];
+    if (valid) {
+        src = block_source(g, strip, tid);
+        if (FAST) load_block_rows(fbase, src, raw);
+    }
+    for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
+    if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
+    if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = a.tab->slot[tid - 32];
+    for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
+    __syncthreads();
 
-        // ---- table loads first, then every pixel load of this lane's block (8 rows x 24 B): the
-        //      in-order vmcnt then lets the tables be consumed while the pixels are still in flight ----
-        constexpr int kLutRegs = 3;
-        uint32_t lutv[kLutRegs];
-        const bool lut_in_regs = base == 0 && T * kLutRegs >= kLutWords;
-        if (lut_in_regs) {
-#pragma unroll
-            for (int j = 0; j < kLutRegs; j++) {
-                int idx = tid + j * T;
-                lutv[j] = idx < kLutWords ? a.tab->ac[idx] : 0u;
-            }
-        }
-        BlockSrc src;
-        Row24 raw[8];
-        if (valid) {
-            src = block_source(g, strip, bidx);
-            if (FAST) {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    raw[i] = *reinterpret_cast<const Row24 *>(fbase + (src.first + (long long)i * src.stride) * 3);
-            }
-        }
+    unsigned long long nz = 0;
+    int dc = 0;
+    if (valid) dc = block_to_stage<FAST, false>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
+    auto fetch = [&](int p) -> int { return fetch_level<false>(slot_lut, stage, T, tid, p); };
 
-        // ---- workgroup prologue, under the latency of those loads ----
-        if (base == 0) {
-            if (lut_in_regs) {
-#pragma unroll
-                for (int j = 0; j < kLutRegs; j++) {
-                    int idx = tid + j * T;
-                    if (idx < kLutWords) ac_lut[idx] = lutv[j];
-                }
+    uint32_t hdr = 0;
+    int hlen = 0;
+    unsigned long long emit = 0;
+    BlockBits bb = {0, 0, 0, false};
+    bool ok = true;
+    if (valid) {
+        dc_header(dc, src.comp == 0, src.blk, dc_lut, hdr, hlen);
+        emit = emit_set(nz);
+        auto sink = [&](uint32_t code, int bits) {
+            bb.tot += bits;
+            if (!bb.spilled && bb.nacc + bits <= 64) {
+                bb.acc = (bb.acc << bits) | code;
+                bb.nacc += bits;
             } else {
-                for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
+                bb.spilled = true;
             }
-            if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
-            if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = a.tab->slot[tid - 32];
-            for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
-            __syncthreads();
-            // slice header (mpeg1_blk.c:12-16): 00 00 01, strip+1 (uint8 wrap), quant_scale=1 in 5 bits, a 0 bit
-            if (tid == 0) {
-                image[0] = 0x00000100u | ((uint32_t)(strip + 1) & 0xffu);
-                image[1] = 0x08000000u; // 00001 0 followed by zeros
-            }
-        }
-        STAMP(0);
-
-        // ---- rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise +
-        //      stage in LDS + non-zero mask, one column at a time (nothing but rows[] stays live) ----
-        unsigned long long nz = 0;
-        int dc = 0, blk = 0, comp = 0;
-        if (valid) {
-            blk = src.blk;
-            comp = src.comp;
-#if M1V_PACK_ROWS
-            // row-pass results (|v| <= 3200) kept as int16 pairs: 32 registers instead of 64
-            uint32_t rp[32];
-#else
-            int rows[64];
-#endif
-            {
-                CompCoefF k = comp_coef_f(src.comp);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    int px[8];
-                    if (FAST)
-                        convert_row24(raw[i], k, px);
-                    else
-                        load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
-#if M1V_PACK_ROWS
-                    int r8[8];
-                    fdct_row(px, r8);
-#pragma unroll
-                    for (int cc = 0; cc < 4; cc++)
-                        rp[i * 4 + cc] = ((uint32_t)r8[2 * cc] & 0xffffu) | ((uint32_t)r8[2 * cc + 1] << 16);
-#else
-                    fdct_row(px, &rows[i * 8]);
-#endif
-                }
-            }
-            STAMP(1);
-            const float *rq_t = a.tab->rq_t;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int c[8], q[8];
-#if M1V_PACK_ROWS
-                int v[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    uint32_t w = rp[r * 4 + (i >> 1)];
-                    v[r] = (i & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
-                }
-                fdct_col(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], c);
-#else
-                fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                         rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c);
-#endif
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    q[u] = quant(c[u], rq_t[i * 8 + u]);
-                    if (q[u] != 0) nz |= 1ull << scan_pos(u * 8 + i);
-                }
-                if (i == 0) dc = q[0];
-#pragma unroll
-                for (int h = 0; h < 4; h++)
-                    stage[(h * 8 + i) * T + tid] = ((uint32_t)q[2 * h] & 0xffffu) | ((uint32_t)q[2 * h + 1] << 16);
-            }
-            STAMP(2);
-        }
-        STAMP(3);
-        auto fetch = [&](int p) -> int {
-            uint32_t e = (slot_lut[p >> 2] >> ((p & 3) * 8)) & 0xffu;
-            uint32_t w = stage[(e >> 1) * T + tid];
-            return (e & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
         };
-
-        // ---- DC part + macroblock header ----
-        uint32_t hdr = 0;
-        int hlen = 0;
-        unsigned long long emit = 0;
-        if (valid) {
-            bool luma = comp == 0;
-            if (dc != 0) { // mpeg1_blk.c:73-93
-                int coe = dc < 0 ? -dc : dc;
-                int low = coe & 0xff;
-                int sz = low ? 32 - __builtin_clz((unsigned)low) : 1;
-                uint32_t e = dc_lut[(luma ? 0 : 16) + sz];
-                if (dc < 0) coe ^= 1 << (sz - 1);
-                hdr = ((e & 0xffffu) << sz) | ((uint32_t)coe & 0xffu & ((1u << sz) - 1u));
-                hlen = (int)(e >> 16) + sz;
-            } else {       // "100" / "00", mpeg1_blk.c:98-102
-                hdr = luma ? 0x4u : 0x0u;
-                hlen = luma ? 3 : 2;
-            }
-            if (blk == 0) { // macroblock_address_increment "1" + type "1"
-                hdr |= 3u << hlen;
-                hlen += 2;
-            }
-            unsigned long long stop = nz & (nz << 1);
-            unsigned long long below = stop ? ((stop & (~stop + 1)) - 1) : ~0ull;
-            emit = nz & ~1ull & below;
-        }
-
-        // ---- pass 1: code words into a 64-bit register (common case) and the block's bit count ----
-        unsigned long long acc = 0;
-        int nacc = 0, tot = 0;
-        bool spilled = false;
-        if (valid) {
-            auto sink = [&](uint32_t code, int bits) {
-                tot += bits;
-                if (!spilled && nacc + bits <= 64) {
-                    acc = (acc << bits) | code;
-                    nacc += bits;
-                } else {
-                    spilled = true;
-                }
-            };
-            ok &= walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
-        }
-
-        STAMP(4);
-        uint32_t chunk_bits;
-        uint32_t off = block_scan_exclusive_1b((uint32_t)tot, wave_sums, parity, T, chunk_bits) + bit_cursor;
-        parity ^= 1;
-        STAMP(5);
-        uint32_t end_bits = bit_cursor + chunk_bits;
-
-        // ---- strip image too large for LDS: continue in the (zeroed) scratch slot ----
-        if (!global_mode && ((end_bits + 63) >> 5) > (uint32_t)a.lds_words) {
-            uint32_t cap_words = g.strip_cap >> 2;
-            for (uint32_t i = tid; i < cap_words; i += T) slot32[i] = 0;
-            __syncthreads();
-            uint32_t have = (bit_cursor + 31) >> 5;
-            for (uint32_t i = tid; i < have; i += T) {
-                uint32_t v = image[i];
-                if (v) atomicOr(&slot32[i], __builtin_bswap32(v));
-            }
-            global_mode = true;
-            __syncthreads();
-        }
-
-        // ---- pass 2: OR the bits in at their final position ----
-        if (valid) {
-            if (!spilled) {
-                unsigned long long A = acc << (64 - nacc);
-                uint32_t w = off >> 5, sh = off & 31u;
-                uint32_t w0 = (uint32_t)(A >> (32 + sh));
-                uint32_t w1 = (uint32_t)(A >> sh);
-                uint32_t w2 = sh ? ((uint32_t)A << (32 - sh)) : 0u;
-                if (!global_mode) {
-                    if (w0) atomicOr(&image[w], w0);
-                    if (w1) atomicOr(&image[w + 1], w1);
-                    if (w2) atomicOr(&image[w + 2], w2);
-                } else {
-                    if (w0) atomicOr(&slot32[w], __builtin_bswap32(w0));
-                    if (w1) atomicOr(&slot32[w + 1], __builtin_bswap32(w1));
-                    if (w2) atomicOr(&slot32[w + 2], __builtin_bswap32(w2));
-                }
-            } else {
-                uint32_t pos = off;
-                if (!global_mode) {
-                    auto sink = [&](uint32_t code, int bits) {
-                        or_code<false>(image, pos, code, bits);
-                        pos += bits;
-                    };
-                    walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
-                } else {
-                    auto sink = [&](uint32_t code, int bits) {
-                        or_code<true>(slot32, pos, code, bits);
-                        pos += bits;
-                    };
-                    walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
-                }
-            }
-        }
-        bit_cursor = end_bits;
-        STAMP(6);
-        __syncthreads(); // stage[] is reused by the next chunk; image writes complete
-        STAMP(7);
-        base += chunk;
-    } while (MULTI && base < blocks_per_strip);
-
-    // ---- store the strip (zero bits pad it to a byte, encoder.h:442-443) ----
-    uint32_t nbytes = (bit_cursor + 7) >> 3;
+        ok = walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
+    }
+    uint32_t strip_bits;
+    uint32_t off = block_scan_exclusive_1b((uint32_t)bb.tot, wave_sums, 0, T, strip_bits) + 38;
+    uint32_t end_bits = 38 + strip_bits;
+    const bool global_mode = ((end_bits + 63) >> 5) > (uint32_t)a.lds_words; // image too large for LDS
+    uint32_t *img = image;
+    if (global_mode) {
+        uint32_t cap_words = g.strip_cap >> 2;
+        for (uint32_t i = tid; i < cap_words; i += T) slot32[i] = 0;
+        __syncthreads();
+        img = slot32;
+    }
+    if (tid == 0) {
+        uint32_t h0 = slice_word0(strip), h1 = kSliceWord1;
+        atomicOr(&img[0], global_mode ? __builtin_bswap32(h0) : h0);
+        atomicOr(&img[1], global_mode ? __builtin_bswap32(h1) : h1);
+    }
+    if (valid) {
+        auto walk = [&](auto &sink) { walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink); };
+        if (global_mode)
+            put_block<true>(slot32, off, bb, walk);
+        else
+            put_block<false>(image, off, bb, walk);
+    }
+    __syncthreads();
+    // store the strip (zero bits pad it to a byte, encoder.h:442-443)
     if (!global_mode) {
-        uint32_t nwords = (bit_cursor + 31) >> 5;
+        uint32_t nwords = (end_bits + 31) >> 5;
         for (uint32_t i = tid; i < nwords; i += T) slot32[i] = __builtin_bswap32(image[i]);
     }
-    if (tid == 0) a.strip_bytes[(unsigned long long)frame * g.n_strips + strip] = nbytes;
+    if (tid == 0) a.strip_bytes[(unsigned long long)frame * g.n_strips + strip] = (end_bits + 7) >> 3;
+    if (!ok) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+}
+
+// ---- kernel 2 (the dominant one): dense runs of blocks -----------------------------------------------
+// The blocks of a frame in emission order (strip-major, then macroblock, then Y0 Y1 Y2 Y3 Cb Cr) are cut
+// into runs of T consecutive blocks, one workgroup (T lanes, no idle lane) per run.  T <= blocks per
+// strip, so a run touches at most two strips: segment 0 (lanes < nA) continues or starts strip s0,
+// segment 1 (lanes >= nA) starts strip s0+1.  Each segment is packed on its own from a word boundary of
+// the workgroup's image (with the 38-bit slice header in front when it starts a strip); k_gather_dense
+// later concatenates the segments of a strip with the necessary bit shift.
+struct DenseArgs {
+    Geometry g;
+    const uint8_t *rgb;
+    const Tables *tab;
+    uint8_t *scratch;       // [frame][run][run_cap]
+    uint32_t *run_meta;     // [frame][run][4]: bits of segment 0, bits of segment 1, first word of segment 1
+    uint32_t *status;
+    int n_frames;
+    int threads;            // T
+    int runs_per_frame;
+    int lds_words;
+    uint32_t run_cap;       // bytes per scratch slot
+    unsigned long long *stamps;
+};
+
+template <bool FAST, bool STAGE8>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(M1V_WAVES_PER_EU, M1V_WAVES_PER_EU)))
+void k_encode_dense(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Geometry &g = a.g;
+    const int T = a.threads;
+    const int tid = threadIdx.x;
+    constexpr int kStageRows = STAGE8 ? 16 : 32;
+    uint32_t *ac_lut = lds;                        // kLutWords
+    uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
+    uint32_t *slot_lut = dc_lut + kDcWords;        // kSlotWords
+    uint32_t *wave_sums = slot_lut + kSlotWords;   // 32 (16 wave totals, [16] = prefix inside the boundary wave)
+    uint32_t *stage = wave_sums + 32;              // kStageRows x T
+    uint32_t *image = stage + kStageRows * T;      // a.lds_words
+
+    int frame, run;
+    frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
+    const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(
+        a.scratch + ((unsigned long long)frame * a.runs_per_frame + run) * a.run_cap);
+
+    STAMP_INIT();
+    const int bps = g.n_mbrows * 6;                 // blocks per strip
+    const int nb = g.n_strips * bps;                // blocks per frame
+    const int first = run * T;                      // first block of the run
+    const int s0 = first / bps;                     // strip of segment 0 (wave-uniform)
+    const int pos0 = first - s0 * bps;              // position of the run's first block inside strip s0
+    const int nA = min(T, bps - pos0);              // lanes of segment 0
+    const int gb = first + tid;
+    const bool valid = gb < nb;
+    const bool in_b = tid >= nA;                    // lane belongs to segment 1 (strip s0 + 1)
+    const bool has_b = first + nA < nb && nA < T;
+
+    // ---- table loads first, then every pixel load of this lane's block: the in-order vmcnt lets the
+    //      tables be consumed while the pixels are still in flight ----
+    constexpr int kLutRegs = 5; // T >= 256 covers the 1280 words
+    uint32_t lutv[kLutRegs];
+    const bool lut_in_regs = T * kLutRegs >= kLutWords;
+    if (lut_in_regs) {
+#pragma unroll
+        for (int j = 0; j < kLutRegs; j++) {
+            int idx = tid + j * T;
+            lutv[j] = idx < kLutWords ? a.tab->ac[idx] : 0u;
+        }
+    }
+    BlockSrc src;
+    Row24 raw[8];
+    if (valid) {
+        int strip = in_b ? s0 + 1 : s0;
+        int pos = in_b ? tid - nA : pos0 + tid;
+        src = block_source(g, strip, pos);
+        if (FAST) load_block_rows(fbase, src, raw);
+    }
+
+    // ---- workgroup prologue, under the latency of those loads ----
+    if (lut_in_regs) {
+#pragma unroll
+        for (int j = 0; j < kLutRegs; j++) {
+            int idx = tid + j * T;
+            if (idx < kLutWords) ac_lut[idx] = lutv[j];
+        }
+    } else {
+        for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
+    }
+    if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
+    if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = STAGE8 ? a.tab->slot8[tid - 32] : a.tab->slot[tid - 32];
+    for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
+    __syncthreads();
+    STAMP(0);
+
+    unsigned long long nz = 0;
+    int dc = 0;
+    if (valid) dc = block_to_stage<FAST, STAGE8>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
+    STAMP(2);
+    auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(slot_lut, stage, T, tid, p); };
+
+    uint32_t hdr = 0;
+    int hlen = 0;
+    unsigned long long emit = 0;
+    BlockBits bb = {0, 0, 0, false};
+    bool ok = true;
+    if (valid) {
+        dc_header(dc, src.comp == 0, src.blk, dc_lut, hdr, hlen);
+        emit = emit_set(nz);
+        auto sink = [&](uint32_t code, int bits) {
+            bb.tot += bits;
+            if (!bb.spilled && bb.nacc + bits <= 64) {
+                bb.acc = (bb.acc << bits) | code;
+                bb.nacc += bits;
+            } else {
+                bb.spilled = true;
+            }
+        };
+        ok = walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
+    }
+    STAMP(4);
+
+    // ---- exclusive scan of the bit counts; PA = bits of segment 0's blocks ----
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t incl = wave_scan_inclusive((uint32_t)bb.tot);
+    if (lane == kWave - 1) wave_sums[wave] = incl;
+    if (tid == nA - 1) wave_sums[16] = incl;       // prefix inside the wave that holds segment 0's last lane
+    __syncthreads();
+    const int nw = T >> 6;
+    uint32_t wsum = lane < nw ? wave_sums[lane] : 0;
+    uint32_t wincl = row_scan_inclusive(wsum);
+    uint32_t wave_off = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wsum), wave);
+    uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, nw - 1);
+    const int wA = __builtin_amdgcn_readfirstlane((nA - 1) >> 6);
+    uint32_t PA = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wsum), wA) + wave_sums[16];
+    uint32_t P = wave_off + incl - (uint32_t)bb.tot;
+    STAMP(5);
+
+    const uint32_t origin0 = pos0 == 0 ? 38u : 0u;          // segment 0 starts its strip
+    const uint32_t bits0 = origin0 + PA;
+    const uint32_t base1 = ((bits0 + 31) >> 5) + 1;         // first image word of segment 1
+    const uint32_t bits1 = has_b ? 38u + (total - PA) : 0u;
+    const uint32_t end_words = has_b ? base1 + ((bits1 + 31) >> 5) : ((bits0 + 31) >> 5);
+    const uint32_t off = in_b ? base1 * 32u + 38u + (P - PA) : origin0 + P;
+
+    // ---- image too large for LDS: build it in the (zeroed) scratch slot with global atomics ----
+    const bool global_mode = end_words + 2 > (uint32_t)a.lds_words;
+    if (global_mode) {
+        uint32_t cap_words = a.run_cap >> 2;
+        for (uint32_t i = tid; i < cap_words; i += T) slot32[i] = 0;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t *img = global_mode ? slot32 : image;
+        if (pos0 == 0) {
+            uint32_t h0 = slice_word0(s0), h1 = kSliceWord1;
+            atomicOr(&img[0], global_mode ? __builtin_bswap32(h0) : h0);
+            atomicOr(&img[1], global_mode ? __builtin_bswap32(h1) : h1);
+        }
+        if (has_b) {
+            uint32_t h0 = slice_word0(s0 + 1), h1 = kSliceWord1;
+            atomicOr(&img[base1], global_mode ? __builtin_bswap32(h0) : h0);
+            atomicOr(&img[base1 + 1], global_mode ? __builtin_bswap32(h1) : h1);
+        }
+        uint32_t *m = a.run_meta + ((unsigned long long)frame * a.runs_per_frame + run) * 4;
+        m[0] = bits0;
+        m[1] = bits1;
+        m[2] = base1;
+    }
+    if (valid) {
+        auto walk = [&](auto &sink) { walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink); };
+        if (global_mode)
+            put_block<true>(slot32, off, bb, walk);
+        else
+            put_block<false>(image, off, bb, walk);
+    }
+    STAMP(6);
+    __syncthreads();
+    STAMP(7);
+    if (!global_mode)
+        for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
     if (!ok) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
     STAMP(8);
 }
@@ -957,6 +1106,102 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
             uint8_t v = a.tab->hdr[(a.first_index + f) & 255][t];
             // encoder.h:448-453: (u16)(bytes after the length field's word) - 4
             uint32_t fwd = (uint32_t)((fs - 4ull) - 4ull - 4ull) & 0xffffu;
+            if (t == 4) v = (uint8_t)(fwd >> 8);
+            if (t == 5) v = (uint8_t)(fwd & 0xff);
+            a.out[fo + t] = v;
+        } else if (t < 48) {
+            a.out[fo + fs - 4 + (t - 44)] = 0; // encoder.h:456-458 (observed zero)
+        }
+    }
+}
+
+// ---- dense path: strips are concatenations of run segments ----------------------------------------
+struct DenseGeom {
+    int n_frames, n_strips, bps, T, runs_per_frame;
+    uint32_t run_cap;
+};
+
+// Segment of strip s contributed by run w: which of the run's two segments, its bit count, its bytes.
+__device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint32_t *meta_frame, int w, int s,
+                                                  uint32_t &byte_off_in_slot) {
+    int s0w = (w * d.T) / d.bps;
+    const uint32_t *m = meta_frame + (size_t)w * 4;
+    if (s0w == s) {
+        byte_off_in_slot = 0;
+        return m[0];
+    }
+    byte_off_in_slot = m[2] * 4u;
+    return m[1];
+}
+
+__global__ __launch_bounds__(256) void k_dense_strip_bytes(DenseGeom d, const uint32_t *run_meta,
+                                                           uint32_t *strip_bytes) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_frames * d.n_strips) return;
+    int f = i / d.n_strips, s = i - f * d.n_strips;
+    const uint32_t *mf = run_meta + (size_t)f * d.runs_per_frame * 4;
+    int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
+    uint32_t bits = 0, unused;
+    for (int w = w_lo; w <= w_hi; w++) bits += dense_segment(d, mf, w, s, unused);
+    strip_bytes[i] = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+}
+
+struct DenseGatherArgs {
+    DenseGeom d;
+    const uint8_t *scratch;
+    const uint32_t *run_meta, *strip_bytes, *strip_off;
+    const unsigned long long *frame_size, *frame_off;
+    const Tables *tab;
+    uint8_t *out;
+    unsigned long long out_cap;
+    uint32_t *status;
+    int first_index;
+};
+
+__global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
+    const DenseGeom &d = a.d;
+    int s = blockIdx.x, f = blockIdx.y;
+    unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
+    if (fo + fs > a.out_cap) {
+        if (threadIdx.x == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
+        return;
+    }
+    size_t idx = (size_t)f * d.n_strips + s;
+    const uint32_t *mf = a.run_meta + (size_t)f * d.runs_per_frame * 4;
+    const uint8_t *slots = a.scratch + (size_t)f * d.runs_per_frame * d.run_cap;
+    uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
+    uint32_t n = a.strip_bytes[idx];
+    int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
+    // every thread assembles 32 bits of the strip: a 64-bit window of the source segment (word loads from the
+    // word-aligned scratch), funnel-shifted to the destination phase
+    const uint32_t nwords = (n + 3) >> 2;
+    for (uint32_t j = threadIdx.x; j < nwords; j += blockDim.x) {
+        uint32_t lo_bit = 32u * j, hi_bit = lo_bit + 32u, val = 0, D = 0;
+        for (int w = w_lo; w <= w_hi; w++) {
+            uint32_t boff, L = dense_segment(d, mf, w, s, boff);
+            uint32_t lo = max(lo_bit, D), hi = min(hi_bit, D + L);
+            if (lo < hi) { // bits [lo, hi) of the strip come from bits [lo - D, hi - D) of this segment
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(slots + (size_t)w * d.run_cap + boff);
+                uint32_t sb = lo - D, nb = hi - lo, wi = sb >> 5, sh = sb & 31u;
+                unsigned long long win = ((unsigned long long)__builtin_bswap32(src[wi]) << 32) | __builtin_bswap32(src[wi + 1]);
+                uint32_t bits = (uint32_t)((win << sh) >> (64u - nb));
+                val |= bits << (32u - (lo - lo_bit) - nb);
+            }
+            D += L;
+        }
+        uint32_t b0 = 4u * j;
+        uint8_t *o = dst + b0;
+        if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
+            *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
+        } else {
+            for (uint32_t k = 0; k < 4u && b0 + k < n; k++) o[k] = (uint8_t)(val >> (24u - 8u * k));
+        }
+    }
+    if (s == 0) {
+        int t = threadIdx.x;
+        if (t < 44) {
+            uint8_t v = a.tab->hdr[(a.first_index + f) & 255][t];
+            uint32_t fwd = (uint32_t)((fs - 4ull) - 4ull - 4ull) & 0xffffu; // encoder.h:448-453
             if (t == 4) v = (uint8_t)(fwd >> 8);
             if (t == 5) v = (uint8_t)(fwd & 0xff);
             a.out[fo + t] = v;
@@ -1163,6 +1408,12 @@ struct m1v_encoder {
     int qf, mode, max_frames;
     int threads;       // workgroup size of k_encode_strips
     int lds_words;
+    bool dense;        // blocks per strip >= 64: k_encode_dense, else one workgroup per strip
+    bool narrow;       // no AC level can reach +-128: one byte per staged level
+    int dense_T, runs_per_frame;
+    uint32_t run_cap;
+    uint32_t *d_run_meta;
+    size_t scratch_bytes;
     bool fast_ok;      // geometry allows the 4-byte-aligned 24-byte row loads
     Tables *d_tab;
     uint8_t *d_scratch;
@@ -1199,6 +1450,42 @@ size_t m1v_file_prolog(uint8_t out[27]) {
     return 27;
 }
 
+// Chooses the encode kernel geometry and (re)allocates its scratch.  dense_T = 0 picks the default
+// run length: 256 blocks (4 waves = one per SIMD, so that 5 workgroups of 96-VGPR waves share a CU; measured
+// 384/320/256/192/128 -> 1140/1161/837/892/1026 us per 300 x 1080p), or the largest multiple of 64 that the
+// strip holds when it has fewer than 256 blocks.
+static int configure_path(m1v_encoder *e, int dense_T) {
+    const Geometry &g = e->g;
+    int bps = g.n_mbrows * 6;
+    size_t need, meta = 0;
+    if (e->dense) {
+        int T = dense_T > 0 ? dense_T : (bps >= 256 ? 256 : (bps / kWave) * kWave);
+        if (T < kWave || T > 384 || T % kWave || T > bps) return fail(M1V_E_ARG, "bad dense run length%s");
+        e->dense_T = T;
+        int nb = g.n_strips * bps;
+        e->runs_per_frame = (nb + T - 1) / T;
+        // two word-aligned segments of at most T blocks of <= 886 + 2 bits, two slice headers, slack
+        e->run_cap = (uint32_t)(((((size_t)T * (kMaxBlockBits + 2) + 2 * 38 + 3 * 32 + 7) / 8) + 32 + 15) & ~(size_t)15);
+        need = (size_t)e->max_frames * e->runs_per_frame * e->run_cap;
+        meta = (size_t)e->max_frames * e->runs_per_frame * 4 * sizeof(uint32_t);
+    } else {
+        need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
+    }
+    if (need > e->scratch_bytes) {
+        (void)hipFree(e->d_scratch);
+        e->d_scratch = nullptr;
+        e->scratch_bytes = 0;
+        if (hipMalloc(&e->d_scratch, need) != hipSuccess) return fail(M1V_E_HIP, "scratch allocation failed%s");
+        e->scratch_bytes = need;
+    }
+    if (meta) {
+        (void)hipFree(e->d_run_meta);
+        e->d_run_meta = nullptr;
+        if (hipMalloc(&e->d_run_meta, meta) != hipSuccess) return fail(M1V_E_HIP, "metadata allocation failed%s");
+    }
+    return M1V_OK;
+}
+
 int m1v_create(m1v_encoder **out, int device, int width, int height, int channels,
                int quality_factor, int mode, int max_frames) {
     if (!out) return fail(M1V_E_ARG, "null out%s");
@@ -1229,8 +1516,13 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     unsigned long long strip_bits = 38ull + (unsigned long long)g.n_mbrows * (2 + 6 * kMaxBlockBits);
     g.strip_cap = (uint32_t)((((strip_bits + 7) / 8) + 16 + 15) & ~15ull);
     int bps = g.n_mbrows * 6;
-    e->threads = bps >= kMaxThreads ? kMaxThreads : ((bps + kWave - 1) / kWave) * kWave;
-    e->lds_words = kDefaultLdsWords;
+    e->threads = kWave;               // strip-per-workgroup kernel: only used when bps < 64
+    e->lds_words = 0;                 // 0 = default of the kernel in use
+    e->dense = bps >= kWave;
+    e->dense_T = 0;
+    e->d_run_meta = nullptr;
+    e->d_scratch = nullptr;
+    e->scratch_bytes = 0;
     e->fast_ok = channels == 3 && (width % 8) == 0;
     e->prof = false;
     e->ev_used = 0;
@@ -1242,12 +1534,21 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     for (int k = 0; k < 64; k++) t->rq[k] = (float)((1.0 / q[k]) * (1.0 + 1.0 / 1048576.0));
     for (int u = 0; u < 8; u++)
         for (int i = 0; i < 8; i++) t->rq_t[i * 8 + u] = t->rq[u * 8 + i];
+    // One byte per staged level is exact iff no AC level can reach +-128.  |AC coefficient| of the
+    // reference's FDCT on u8 pixels stays below 1000 (tests/test_host_tables.py::test_fdct_output_range,
+    // every basis sign pattern), so 128 * (smallest AC divisor) >= 1024 suffices: quality factors <= 76.
+    int min_ac = q[1];
+    for (int k = 1; k < 64; k++) min_ac = q[k] < min_ac ? q[k] : min_ac;
+    e->narrow = min_ac >= 8;
     build_ac_lut(t->ac);
     build_dc_lut(t->dc);
     for (int w = 0; w < 16; w++) {
         uint32_t v = 0;
         for (int b = 0; b < 4; b++) v |= (uint32_t)stage_slot(4 * w + b) << (8 * b);
         t->slot[w] = v;
+        uint32_t v8 = 0;
+        for (int b = 0; b < 4; b++) v8 |= (uint32_t)stage_slot8(4 * w + b) << (8 * b);
+        t->slot8[w] = v8;
     }
     for (int h = 0; h < 256; h++) build_frame_header(t->hdr[h], width, height, h);
 
@@ -1255,7 +1556,6 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = hipMemcpy(e->d_tab, t, sizeof(Tables), hipMemcpyHostToDevice);
     delete t;
     size_t nslots = (size_t)max_frames * g.n_strips;
-    if (err == hipSuccess) err = hipMalloc(&e->d_scratch, nslots * g.strip_cap);
     if (err == hipSuccess) err = hipMalloc(&e->d_strip_bytes, nslots * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMalloc(&e->d_strip_off, nslots * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMalloc(&e->d_frame_size, (size_t)max_frames * 8);
@@ -1265,19 +1565,12 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 16 * 8);
     if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
 #endif
-    // strips of tall pictures need more than the default 64 KiB of dynamic LDS
-    if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<true, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<false, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_strips<false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) err = configure_path(e, 0) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
+    const void *kernels[] = {(const void *)&k_encode_dense<true, true>,  (const void *)&k_encode_dense<true, false>,
+                             (const void *)&k_encode_dense<false, true>, (const void *)&k_encode_dense<false, false>,
+                             (const void *)&k_encode_strips<true>,       (const void *)&k_encode_strips<false>};
+    for (const void *kf : kernels)
+        if (err == hipSuccess) err = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) {
         fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
         m1v_destroy(e);
@@ -1299,6 +1592,7 @@ void m1v_destroy(m1v_encoder *e) {
     (void)hipFree(e->d_frame_off);
     (void)hipFree(e->d_status);
     (void)hipFree(e->d_stamps);
+    (void)hipFree(e->d_run_meta);
     delete e;
 }
 
@@ -1314,9 +1608,16 @@ size_t m1v_frame_bound(const m1v_encoder *e) {
 
 int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
-    e->lds_words = words > 0 ? words : kDefaultLdsWords;
-    if (e->lds_words < 4) e->lds_words = 4;
+    e->lds_words = words > 0 ? (words < 4 ? 4 : words) : 0;
     return M1V_OK;
+}
+
+int m1v_debug_set_dense_threads(m1v_encoder *e, int threads) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    if (!e->dense) return M1V_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return configure_path(e, threads);
 }
 
 #ifdef M1V_STAMPS
@@ -1383,34 +1684,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         return M1V_OK;
     }
     const Geometry &g = e->g;
-    EncodeArgs a;
-    a.g = g;
-    a.rgb = d_rgb;
-    a.tab = e->d_tab;
-    a.scratch = e->d_scratch;
-    a.strip_bytes = e->d_strip_bytes;
-    a.status = e->d_status;
-    a.n_frames = n_frames;
-    a.threads = e->threads;
-    a.lds_words = e->lds_words;
-    a.stamps = e->d_stamps;
-    size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + 32 * e->threads + e->lds_words) * 4;
-    if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
-    dim3 grid((unsigned)((size_t)n_frames * g.n_strips)), block((unsigned)e->threads);
-    if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
-    const bool multi = g.n_mbrows * 6 > (e->threads / 6) * 6;
     const bool fast = fast_path(e, d_rgb);
-    if (fast && !multi)
-        hipLaunchKernelGGL((k_encode_strips<true, false>), grid, block, lds, st, a);
-    else if (!fast && !multi)
-        hipLaunchKernelGGL((k_encode_strips<false, false>), grid, block, lds, st, a);
-    else if (fast)
-        hipLaunchKernelGGL((k_encode_strips<true, true>), grid, block, lds, st, a);
-    else
-        hipLaunchKernelGGL((k_encode_strips<false, true>), grid, block, lds, st, a);
-    if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
-    HIP_TRY(hipGetLastError());
-
     LayoutArgs l;
     l.strip_bytes = e->d_strip_bytes;
     l.strip_off = e->d_strip_off;
@@ -1420,25 +1694,107 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.out_total = (unsigned long long *)d_total;
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
-    hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, st, l);
-    hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, st, l);
 
-    GatherArgs ga;
-    ga.scratch = e->d_scratch;
-    ga.strip_bytes = e->d_strip_bytes;
-    ga.strip_off = e->d_strip_off;
-    ga.frame_size = e->d_frame_size;
-    ga.frame_off = e->d_frame_off;
-    ga.tab = e->d_tab;
-    ga.out = d_out;
-    ga.out_cap = out_cap;
-    ga.status = e->d_status;
-    ga.strip_cap = g.strip_cap;
-    ga.n_frames = n_frames;
-    ga.n_strips = g.n_strips;
-    ga.first_index = first_frame_index;
-    hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, st, ga);
-    HIP_TRY(hipGetLastError());
+    if (e->dense) {
+        DenseArgs a;
+        a.g = g;
+        a.rgb = d_rgb;
+        a.tab = e->d_tab;
+        a.scratch = e->d_scratch;
+        a.run_meta = e->d_run_meta;
+        a.status = e->d_status;
+        a.n_frames = n_frames;
+        a.threads = e->dense_T;
+        a.runs_per_frame = e->runs_per_frame;
+        // LDS image of the run's bits: zeroing it is ~3 % of the kernel per KiB-word, outgrowing it costs the
+        // slow global-atomics path.  A run of 256 blocks needs ~230 words at quality 12 on noise; scale the
+        // default with the quantiser (finer quantisers emit more bits per block).
+        a.lds_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 1024 : (e->qf <= 50 ? 2048 : 4096));
+        a.run_cap = e->run_cap;
+        a.stamps = e->d_stamps;
+        const int rows = e->narrow ? 16 : 32;
+        size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + rows * e->dense_T + a.lds_words) * 4;
+        if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
+        dim3 grid((unsigned)((size_t)n_frames * e->runs_per_frame)), block((unsigned)e->dense_T);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        if (fast && e->narrow)
+            hipLaunchKernelGGL((k_encode_dense<true, true>), grid, block, lds, st, a);
+        else if (fast)
+            hipLaunchKernelGGL((k_encode_dense<true, false>), grid, block, lds, st, a);
+        else if (e->narrow)
+            hipLaunchKernelGGL((k_encode_dense<false, true>), grid, block, lds, st, a);
+        else
+            hipLaunchKernelGGL((k_encode_dense<false, false>), grid, block, lds, st, a);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        HIP_TRY(hipGetLastError());
+
+        DenseGeom d;
+        d.n_frames = n_frames;
+        d.n_strips = g.n_strips;
+        d.bps = g.n_mbrows * 6;
+        d.T = e->dense_T;
+        d.runs_per_frame = e->runs_per_frame;
+        d.run_cap = e->run_cap;
+        int total_strips = n_frames * g.n_strips;
+        hipLaunchKernelGGL(k_dense_strip_bytes, dim3((total_strips + 255) / 256), dim3(256), 0, st, d, e->d_run_meta,
+                           e->d_strip_bytes);
+        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, st, l);
+        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, st, l);
+        DenseGatherArgs ga;
+        ga.d = d;
+        ga.scratch = e->d_scratch;
+        ga.run_meta = e->d_run_meta;
+        ga.strip_bytes = e->d_strip_bytes;
+        ga.strip_off = e->d_strip_off;
+        ga.frame_size = e->d_frame_size;
+        ga.frame_off = e->d_frame_off;
+        ga.tab = e->d_tab;
+        ga.out = d_out;
+        ga.out_cap = out_cap;
+        ga.status = e->d_status;
+        ga.first_index = first_frame_index;
+        hipLaunchKernelGGL(k_gather_dense, dim3(g.n_strips, n_frames), dim3(256), 0, st, ga);
+        HIP_TRY(hipGetLastError());
+    } else {
+        EncodeArgs a;
+        a.g = g;
+        a.rgb = d_rgb;
+        a.tab = e->d_tab;
+        a.scratch = e->d_scratch;
+        a.strip_bytes = e->d_strip_bytes;
+        a.status = e->d_status;
+        a.n_frames = n_frames;
+        a.threads = e->threads;
+        a.lds_words = e->lds_words > 0 ? e->lds_words : kDefaultLdsWords;
+        a.stamps = e->d_stamps;
+        size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + 32 * e->threads + a.lds_words) * 4;
+        dim3 grid((unsigned)((size_t)n_frames * g.n_strips)), block((unsigned)e->threads);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        if (fast)
+            hipLaunchKernelGGL(k_encode_strips<true>, grid, block, lds, st, a);
+        else
+            hipLaunchKernelGGL(k_encode_strips<false>, grid, block, lds, st, a);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, st, l);
+        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, st, l);
+        GatherArgs ga;
+        ga.scratch = e->d_scratch;
+        ga.strip_bytes = e->d_strip_bytes;
+        ga.strip_off = e->d_strip_off;
+        ga.frame_size = e->d_frame_size;
+        ga.frame_off = e->d_frame_off;
+        ga.tab = e->d_tab;
+        ga.out = d_out;
+        ga.out_cap = out_cap;
+        ga.status = e->d_status;
+        ga.strip_cap = g.strip_cap;
+        ga.n_frames = n_frames;
+        ga.n_strips = g.n_strips;
+        ga.first_index = first_frame_index;
+        hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, st, ga);
+        HIP_TRY(hipGetLastError());
+    }
     if (d_status)
         HIP_TRY(hipMemcpyAsync(d_status, e->d_status, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     return M1V_OK;

@@ -50,7 +50,7 @@ class Mpeg1Encoder:
         self.blocks_per_frame = self.strips * self.mb_rows * 6
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) is not None and self._h.value and _ffi is not None and C is not None:
             _ffi.lib().m1v_destroy(self._h)
             self._h = C.c_void_p(0)
 
@@ -174,6 +174,11 @@ class Mpeg1Encoder:
 
     def debug_set_lds_words(self, words):
         _ffi.lib().m1v_debug_set_lds_words(self._h, int(words))
+
+    def debug_set_dense_threads(self, threads):
+        rc = _ffi.lib().m1v_debug_set_dense_threads(self._h, int(threads))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_debug_set_dense_threads")
 
 
 def file_prolog():

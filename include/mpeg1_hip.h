@@ -118,6 +118,9 @@ int m1v_profile_read(m1v_encoder *enc, int *launches, double *total_ms);
 /* Test hook: capacity in 32-bit words of the per-strip LDS bit buffer (0 = default).  A tiny value
  * forces the global-memory fallback path so that tests can cover it. */
 int m1v_debug_set_lds_words(m1v_encoder *enc, int words);
+/* Tuning/test hook: blocks per workgroup of the dense encode kernel (multiple of 64, 64..384, not more than
+ * the blocks of one strip; 0 = default). */
+int m1v_debug_set_dense_threads(m1v_encoder *enc, int threads);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,9 @@ import torch
 vp = C.c_void_p
 libs = {}
 for nm in a.names:
-    path = os.path.join(ROOT, "ec504_imageencoder_amd", "libencoder.so") if nm == "base" else os.path.join(ROOT, "build", f"libencoder_{nm}.so")
+    parts = nm.split(":")                      # "name[:T[:W]]" = library variant, dense run length T, LDS image words W
+    lib_nm, dense_t, lds_w = parts[0], (parts[1] if len(parts) > 1 else ""), (parts[2] if len(parts) > 2 else "")
+    path = os.path.join(ROOT, "ec504_imageencoder_amd", "libencoder.so") if lib_nm == "base" else os.path.join(ROOT, "build", f"libencoder_{lib_nm}.so")
     L = C.CDLL(path)
     L.m1v_create.argtypes = [C.POINTER(vp)] + [C.c_int] * 7
     L.m1v_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]
@@ -33,6 +35,12 @@ for nm in a.names:
     h = vp()
     rc = L.m1v_create(C.byref(h), 0, a.w, a.h, 3, 12, 1, a.n)
     assert rc == 0, L.m1v_last_error()
+    if dense_t:
+        L.m1v_debug_set_dense_threads.argtypes = [vp, C.c_int]
+        assert L.m1v_debug_set_dense_threads(h, int(dense_t)) == 0, L.m1v_last_error()
+    if lds_w:
+        L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
+        L.m1v_debug_set_lds_words(h, int(lds_w))
     libs[nm] = (L, h)
 rgb = torch.empty((a.n, a.h, a.w, 3), dtype=torch.uint8, device="cuda")
 L0, h0 = libs[a.names[0]]
