@@ -37,6 +37,21 @@ def cpu_baseline(W, H, qf, seed, budget_s=12.0):
             "sample": f"{n} x {W}x{H} synthetic frames, FULL region, qf {qf}, oracle/mpeg1_oracle.c single thread, {dt:.1f} s"}
 
 
+def pmc_traffic(W, H, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, written from tools/pmc.sh output): (2 x FETCH_SIZE + WRITE_SIZE) KiB — on
+    gfx950 FETCH_SIZE counts half of the bytes of wide reads (MI355X_MICROARCH.md, HBM section).  PMC cannot be
+    collected from inside this process, so this is the committed measurement of the same workload, or null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            rec = json.load(f)
+        if [rec["width"], rec["height"], rec["frames"]] == [W, H, n]:
+            return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,8 +151,8 @@ def main():
                        "global_frames": n * world, "bytes_out_per_frame": round(out_per_frame, 1),
                        "parallelism": f"frames sharded {n}/GPU" + (", RCCL gather of bitstreams to rank 0" if distributed else "")},
             "verified_vs_oracle": verified,
-            "roofline": {"bound": "hbm", "kernel": "k_encode_strips", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(W, H, n),
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_frame * n)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -41,7 +41,6 @@ namespace {
 // constant geometry
 // ------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
-constexpr int kMaxThreads = 1024;
 constexpr int kAcRows = 32, kAcCols = 40;         // AC lookup: [run-1][|level|-1]
 constexpr int kLutWords = kAcRows * kAcCols;      // 1280
 constexpr int kDcWords = 32;                      // 2 x 9 used
@@ -157,39 +156,23 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
     return c;
 }
 
-// The rare exact path as a real (non-inlined) function: keeps ~20 fp64 instructions x 64 pixels and eight
-// per-lane fp64 constants out of the hot instruction stream.  rgb = r | g << 8 | b << 16.
-#ifndef M1V_SLOW_CALL
-#define M1V_SLOW_CALL 0
-#endif
-__device__ __attribute__((noinline)) int component_exact_call(uint32_t rgb, int comp) {
-    CompCoef d = comp_coef(comp);
-    return component_fp64((int)(rgb & 0xffu), (int)((rgb >> 8) & 0xffu), (int)((rgb >> 16) & 0xffu), d.k0, d.kr, d.kg,
-                          d.kb);
-}
-
 // fp32 coefficients of the same three formulas, for the fast path below.  k0 carries -kEps.
-typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr float kEps = 1.5e-4f;
 struct CompCoefF {
-    float2v k0, kr, kg, kb; // both halves equal: operands of the packed (2 pixels per instruction) FMAs
+    float k0, kr, kg, kb;
     int comp;
 };
 __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     CompCoefF c;
-    float k0 = (comp == 0 ? 0.0f : 128.0f) - kEps;
-    float kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
-    float kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
-    float kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
-    c.k0 = float2v{k0, k0};
-    c.kr = float2v{kr, kr};
-    c.kg = float2v{kg, kg};
-    c.kb = float2v{kb, kb};
+    c.k0 = (comp == 0 ? 0.0f : 128.0f) - kEps;
+    c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
+    c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
+    c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
     c.comp = comp;
     return c;
 }
 
-// Same value as component_fp64 for every (r,g,b), at fp32 cost, two pixels at a time.
+// Same value as component_fp64 for every (r,g,b), at fp32 cost.
 // The exact rational value x of a formula is a multiple of 1e-6 in [0.5, 255.5].  Three fp32 FMAs
 // starting from k0 - eps give t with |t - (x - eps)| <= d, d = 6e-5 (three half-ulps of 2^-16, three
 // coefficient roundings of 150 * 2^-24, the rounding of k0 - eps); the reference's fp64 result differs
@@ -198,104 +181,49 @@ __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
 // Otherwise (x within 3.6e-4 of an integer: < 0.1 % of pixels, among them exactly the ties where fp64
 // rounding decides the byte) the lane re-evaluates the reference's fp64 expression.
 // tests: all 2^24 triples x 3 components on the GPU.
-// Tuning switches (tools/ab.py builds variants with -D...):
-//   M1V_COLOUR_PK    1: two pixels per v_pk_fma_f32;   0: scalar FMAs
-//   M1V_SLOW_PIN     1: opaque asm keeps the rare path's byte extraction inside its branch
-//   M1V_ROW_BRANCH   1: one "any pixel of this row uncertain?" branch per 8 pixels, per-pixel fix-ups inside
-#ifndef M1V_COLOUR_PK
-#define M1V_COLOUR_PK 0
-#endif
-#ifndef M1V_ROW_BRANCH
-#define M1V_ROW_BRANCH 1
-#endif
-#ifndef M1V_SLOW_PIN
-#define M1V_SLOW_PIN 0
-#endif
-
-// `slow(i)` must return the exact fp64 component of pixel i (0 or 1); it runs only in the rare branch.
-template <typename Slow>
-__device__ __forceinline__ void component2(uint32_t r0, uint32_t g0, uint32_t b0, uint32_t r1, uint32_t g1,
-                                           uint32_t b1, const CompCoefF &k, int &q0, int &q1, Slow slow) {
-    constexpr float lim = 1.0f - 2.0f * kEps;
-#if M1V_COLOUR_PK
-    float2v t = __builtin_elementwise_fma(float2v{(float)b0, (float)b1}, k.kb, k.k0);
-    t = __builtin_elementwise_fma(float2v{(float)g0, (float)g1}, k.kg, t);
-    t = __builtin_elementwise_fma(float2v{(float)r0, (float)r1}, k.kr, t);
-    float t0 = t.x, t1 = t.y;
-#else
-    float t0 = fmaf((float)b0, k.kb.x, k.k0.x);
-    t0 = fmaf((float)g0, k.kg.x, t0);
-    t0 = fmaf((float)r0, k.kr.x, t0);
-    float t1 = fmaf((float)b1, k.kb.x, k.k0.x);
-    t1 = fmaf((float)g1, k.kg.x, t1);
-    t1 = fmaf((float)r1, k.kr.x, t1);
-#endif
-    q0 = (int)t0;
-    q1 = (int)t1;
-    float h0 = __builtin_amdgcn_fractf(t0), h1 = __builtin_amdgcn_fractf(t1);
-    if (!(h0 <= lim)) q0 = slow(0);
-    if (!(h1 <= lim)) q1 = slow(1);
+// One pixel through the fast path; `bad` tells the caller to redo it with component_fp64.
+__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, bool &bad) {
+    float t = fmaf((float)b, k.kb, k.k0);
+    t = fmaf((float)g, k.kg, t);
+    t = fmaf((float)r, k.kr, t);
+    bad = !(__builtin_amdgcn_fractf(t) <= 1.0f - 2.0f * kEps);
+    return (int)t;
 }
 __device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
-    int q0, q1;
-    component2(r, g, b, r, g, b, k, q0, q1, [&](int) {
+    bool bad;
+    int q = component_fast(r, g, b, k, bad);
+    if (bad) {
         CompCoef d = comp_coef(k.comp);
-        return component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
-    });
-    return q0;
+        q = component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
+    }
+    return q;
 }
 
 struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
 
-// 8 pixels of one block row (24 bytes already in registers) -> 8 component values
+// 8 pixels of one block row (24 bytes already in registers) -> 8 component values.
+// One "is any pixel of this row uncertain?" branch per row instead of one per pixel: the branch is taken by
+// ~35 % of the waves, and then only the flagged pixels redo the fp64 expression (measured +6 % over
+// per-pixel branches: fewer scalar branch round trips in every wave's instruction stream).
 __device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k, int out[8]) {
     auto chan = [&](int j, int ch) -> uint32_t {
         int byte = 3 * j + ch;
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
-    auto slow_px = [&](int j) -> int {
-        uint32_t e[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            int byte = 3 * j + ch;
-            uint32_t w = v.d[byte >> 2];
-#if M1V_SLOW_PIN
-            asm volatile("" : "+v"(w));
-#endif
-            e[ch] = (w >> ((byte & 3) * 8)) & 0xffu;
-        }
-#if M1V_SLOW_CALL
-        return component_exact_call(e[0] | (e[1] << 8) | (e[2] << 16), k.comp);
-#else
-        CompCoef d = comp_coef(k.comp);
-        return component_fp64((int)e[0], (int)e[1], (int)e[2], d.k0, d.kr, d.kg, d.kb);
-#endif
-    };
-#if M1V_ROW_BRANCH
-    constexpr float lim = 1.0f - 2.0f * kEps;
     bool bad[8], any = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        float t = fmaf((float)chan(j, 2), k.kb.x, k.k0.x);
-        t = fmaf((float)chan(j, 1), k.kg.x, t);
-        t = fmaf((float)chan(j, 0), k.kr.x, t);
-        out[j] = (int)t;
-        bad[j] = !(__builtin_amdgcn_fractf(t) <= lim);
+        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, bad[j]);
         any |= bad[j];
     }
-    if (any) { // rare for the wave (~35 % of rows), then only the flagged pixels redo the fp64 expression
+    if (any) {
+        CompCoef d = comp_coef(k.comp);
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (bad[j]) out[j] = slow_px(j);
+            if (bad[j]) out[j] = component_fp64((int)chan(j, 0), (int)chan(j, 1), (int)chan(j, 2), d.k0, d.kr, d.kg, d.kb);
     }
-#else
-#pragma unroll
-    for (int j = 0; j < 8; j += 2)
-        component2(chan(j, 0), chan(j, 1), chan(j, 2), chan(j + 1, 0), chan(j + 1, 1), chan(j + 1, 2), k, out[j],
-                   out[j + 1], [&](int which) { return slow_px(j + which); });
-#endif
 }
 
 // 8 pixels of one block row -> 8 component values.  FAST: C == 3 and the row starts 4-byte aligned.
@@ -1535,8 +1463,9 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     for (int u = 0; u < 8; u++)
         for (int i = 0; i < 8; i++) t->rq_t[i * 8 + u] = t->rq[u * 8 + i];
     // One byte per staged level is exact iff no AC level can reach +-128.  |AC coefficient| of the
-    // reference's FDCT on u8 pixels stays below 1000 (tests/test_host_tables.py::test_fdct_output_range,
-    // every basis sign pattern), so 128 * (smallest AC divisor) >= 1024 suffices: quality factors <= 76.
+    // reference's FDCT on u8 pixels is at most 1022 (127.5 * 8 + the +2 rounding bias, reached at (0,4), (4,0),
+    // (4,4); tests/test_host_tables.py::test_fdct_output_range), so 128 * (smallest AC divisor) >= 1024
+    // suffices: quality factors <= 76.
     int min_ac = q[1];
     for (int k = 1; k < 64; k++) min_ac = q[k] < min_ac ? q[k] : min_ac;
     e->narrow = min_ac >= 8;

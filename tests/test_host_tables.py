@@ -28,6 +28,23 @@ def test_fdct_output_range(orc):
             blocks.append(((pat > 0) * 255).astype(np.uint8))
             blocks.append(((pat < 0) * 255).astype(np.uint8))
     blocks += [rng.integers(0, 2, 64).astype(np.uint8) * 255 for _ in range(2000)]
+    worst_ac = 0
     for b in blocks:
-        worst = max(worst, int(np.abs(orc.fdct(b)).max()))
+        d = orc.fdct(b)
+        worst = max(worst, int(np.abs(d).max()))
+        worst_ac = max(worst_ac, int(np.abs(d[1:]).max()))
     assert worst < (1 << 13), worst
+    # The dense kernel stages AC levels as single bytes whenever 128 * (smallest AC divisor) >= 1024
+    # (m1v_create): that needs every |AC coefficient| < 1024.  An AC coefficient is a zero-mean linear form of
+    # the pixels with sum |b| <= 8 (Cauchy-Schwarz, orthonormal basis), so |AC| <= 127.5 * 8 + 2 (the
+    # reference's rounding bias) = 1022, reached by the sign patterns of (0,4), (4,0), (4,4), which the integer
+    # FDCT computes with adds and shifts only.
+    assert worst_ac == 1022, worst_ac
+
+
+def test_narrow_staging_threshold(orc):
+    """Quality factors for which no AC level can reach +-128 (one byte per staged level is exact)."""
+    for qf in range(1, 101):
+        q = orc.scale_qmatrix(qf)
+        narrow = int(q[1:].min()) >= 8
+        assert narrow == (qf <= 76), qf

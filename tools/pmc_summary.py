@@ -11,7 +11,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if "k_encode_strips" in k: k = "k_encode_strips"
+        if "k_encode_dense" in k: k = "k_encode_dense"
         elif "k_gather" in k: k = "k_gather"
         else: continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned *out, float2 *fo) {
     if (OP == 31) BODY("v_cvt_pk_i16_i32 %0, %0, %6\n v_cvt_pk_i16_i32 %1, %1, %6\n v_pack_b32_f16 %2, %2, %7\n v_pack_b32_f16 %3, %3, %7\n")
     if (OP == 32) BODY("v_cndmask_b32 %0, %0, %6, vcc\n v_cndmask_b32 %1, %1, %6, vcc\n v_cndmask_b32 %2, %2, %7, vcc\n v_cndmask_b32 %3, %3, %7, vcc\n")
     if (OP == 33) BODY("v_add_u32_sdwa %0, %0, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %1, %1, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n v_mul_u32_u24_sdwa %2, %2, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_mul_u32_u24_sdwa %3, %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n")
+    if (OP == 34) BODY("v_cmp_ne_u32 vcc, %0, %6\n v_cndmask_b32 %1, %1, %6, vcc\n v_cmp_ne_u32 vcc, %2, %7\n v_cndmask_b32 %3, %3, %7, vcc\n")
+    if (OP == 35) BODY("v_cmp_ne_u32_e64 s[44:45], %0, %6\n v_cndmask_b32_e64 %1, %1, %6, s[44:45]\n v_cmp_ne_u32_e64 s[46:47], %2, %7\n v_cndmask_b32_e64 %3, %3, %7, s[46:47]\n")
+    if (OP == 36) BODY("v_cmp_ne_u32 vcc, %0, %6\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_cmp_ne_u32 vcc, %2, %7\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n")
+    if (OP == 37) BODY("v_mul_f32 %0, %0, %6 clamp\n v_mul_f32 %1, |%1|, %6 clamp\n v_min_u32 %2, %2, %7\n v_min_u32 %3, %3, %7\n")
+    if (OP == 38) BODY("v_bfi_b32 %0, %6, %0, %7\n v_bfi_b32 %1, %6, %1, %7\n v_and_or_b32 %2, %2, %6, %7\n v_and_or_b32 %3, %3, %6, %7\n")
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ (unsigned)b0 ^ (unsigned)b1;
 }
 
@@ -86,5 +91,7 @@ int main() {
     run<27>("v_med3_i32/v_bfe_i32/v_bfi_b32/v_lshl_add_u32", d, f); run<28>("v_cmp_*_e64 -> sgpr", d, f);
     run<29>("v_mov_b32", d, f); run<30>("v_addc_co_u32", d, f); run<31>("v_cvt_pk_i16_i32/v_pack_b32_f16", d, f);
     run<33>("v_add_u32_sdwa/v_mul_u32_u24_sdwa", d, f);
+    run<34>("pair v_cmp(vcc)+v_cndmask_e32(vcc)", d, f); run<35>("pair v_cmp_e64(sgpr)+v_cndmask_e64", d, f);
+    run<36>("pair v_cmp(vcc)+v_addc_co_u32", d, f); run<37>("v_mul_f32 clamp / v_min_u32", d, f); run<38>("v_bfi_b32/v_and_or_b32", d, f);
     return 0;
 }
