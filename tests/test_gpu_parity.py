@@ -239,6 +239,56 @@ def test_long_blocks_and_global_fallback(torch_cuda, orc, qf, npos, amp, big):
         enc.close()
 
 
+@pytest.mark.parametrize("qf", [76, 77])
+def test_extreme_levels_at_the_narrow_staging_boundary(torch_cuda, orc, qf):
+    """Quality 76 is the last one staged as one byte per level (smallest AC divisor 8: |level| <= 1022/8 = 127),
+    77 the first staged as int16.  Blocks made of the sign patterns of the basis functions with the largest
+    coefficients and the smallest divisors exercise the largest levels either side of the switch."""
+    torch = torch_cuda
+    W, H = 256, 144
+    i, j = np.divmod(np.arange(64), 8)
+    pats = []
+    for (u, v) in ((0, 4), (4, 0), (4, 4), (0, 1), (1, 0), (7, 7)):
+        b = np.cos((2 * i + 1) * u * np.pi / 16) * np.cos((2 * j + 1) * v * np.pi / 16)
+        pats += [((b > 0) * 255).astype(np.uint8).reshape(8, 8), ((b < 0) * 255).astype(np.uint8).reshape(8, 8)]
+    rng = np.random.default_rng(qf)
+    pics = []
+    for _ in range(3):
+        pic = np.zeros((H, W, 3), np.uint8)
+        for by in range(0, H, 8):
+            for bx in range(0, W, 8):
+                pic[by:by + 8, bx:bx + 8, :] = pats[rng.integers(len(pats))][..., None]
+        try:
+            orc.encode_frame(pic, W, H, 0, qf, orc.MODE_FULL)
+            pics.append(pic)
+        except ValueError:
+            pass
+    assert pics, "every picture was unencodable"
+    pics = np.stack(pics)
+    co = orc.frame_coefficients(pics[0], W, H, qf, orc.MODE_FULL)
+    # with the default matrix the binding position is (0,1)/(1,0): 924 / 8 = 115 at quality 76, 924 / 7 = 132 at 77
+    assert np.abs(co[:, 1:]).max() >= (128 if qf == 77 else 110)
+    want, wsizes = orc.encode_frames(pics, len(pics), W, H, 0, qf, orc.MODE_FULL)
+    enc = _enc(W, H, qf, "full", max_frames=len(pics))
+    got, sizes = enc.encode_to_bytes(torch.from_numpy(pics).cuda(), 0)
+    assert got == want and sizes == [int(x) for x in wsizes]
+    assert np.array_equal(enc.coefficients(torch.from_numpy(pics).cuda()).cpu().numpy()[0].astype(np.int32), co)
+    enc.close()
+
+
+@pytest.mark.parametrize("threads", [64, 128, 192, 256, 320, 384])
+def test_dense_run_lengths(torch_cuda, orc, threads):
+    """Every supported run length of the dense kernel gives the same bytes (segment stitching at all phases)."""
+    W, H, n = 1920, 1080, 2
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    rgb = enc.synth(n, seed=99)
+    want, wsizes = orc.encode_frames(rgb.cpu().numpy(), n, W, H, 3, 12, orc.MODE_FULL, threads=8)
+    enc.debug_set_dense_threads(threads)
+    got, sizes = enc.encode_to_bytes(rgb, first_frame_index=3)
+    assert got == want and sizes == [int(x) for x in wsizes]
+    enc.close()
+
+
 def test_unencodable_level_is_reported(torch_cuda, orc):
     """|level| >= 256 with run >= 1: the reference dereferences NULL (vlc.c:349 -> bit_vector.c:100).
     The HIP path reports M1V_E_UNENCODABLE instead of producing bytes; the oracle flags the same input."""
