@@ -7,6 +7,6 @@ cd $ROOT/ec504_imageencoder_amd/csrc
 mkdir -p $ROOT/build
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -Rpass-analysis=kernel-resource-usage -c m1v_kernels.hip -o $ROOT/build/m1v_kernels_$NAME.o 2> /tmp/mkvariant_$NAME.log || { grep error /tmp/mkvariant_$NAME.log; exit 1; }
-[ -f encoder_host.o ] || gcc -O2 -fPIC -std=c11 -I../../include -c encoder_host.c -o encoder_host.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libencoder_$NAME.so $ROOT/build/m1v_kernels_$NAME.o encoder_host.o -lm
+make -s encoder_host.o compat_primitives.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libencoder_$NAME.so $ROOT/build/m1v_kernels_$NAME.o encoder_host.o compat_primitives.o -lm
 echo "$NAME: $(grep -A9 'k_encode_stripsILb1ELb0' /tmp/mkvariant_$NAME.log | grep -E ' VGPRs:| ScratchSize' | sed 's/.*remark: *//; s/ \[.*//' | tr '\n' ' ')"
