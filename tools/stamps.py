@@ -24,8 +24,8 @@ L.m1v_debug_read_stamps(enc._h, buf)
 for _ in range(3):
     enc.encode(rgb)
 L.m1v_debug_read_stamps(enc._h, buf)
-names = ["0 prologue (tables, zero image, wait for pixels)", "1 -", "2 convert + FDCT + quantise + stage", "3 -", "4 DC hdr + emit set + pass 1",
-         "5 workgroup scan", "6 pass 2 (OR into image)", "7 end-of-chunk barrier", "8 store strip"]
+names = ["0 prologue (tables, zero image, wait for pixels, barrier)", "1 -", "2 convert + FDCT + quantise + stage", "3 -", "4 DC hdr + emit set + pass 1",
+         "5 workgroup scan (1 barrier)", "6 pass 2 (OR into image)", "7 barrier before the store", "8 store run image"]
 tot = sum(buf[i] for i in range(9))
 for i, nm in enumerate(names):
     print(f"{nm:40s} {buf[i] / tot * 100:6.2f} %   {buf[i] / (3 * (300 * 189 * 4)):10.0f} cycles/wave")
