@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--quality", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true", help="also time the host-buffer (PCIe inclusive) entry point")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 code path on a box with ONE GPU: every rank encodes on cuda:0, "
+                         "the bitstream gather goes through host memory (numbers are not meaningful)")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,14 +81,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.backend == "gloo"
+    gpu_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, n, qf, seed = args.width, args.height, args.frames, args.quality, 504
-    enc = Mpeg1Encoder(W, H, qf, "full", max_frames=n, device=local_rank)
+    enc = Mpeg1Encoder(W, H, qf, "full", max_frames=n, device=gpu_index)
     first = rank * n  # global frame index of this rank's first frame
     rgb = enc.synth(n, seed=seed, first_frame_index=first, device=dev)
     out = torch.empty(enc.default_out_capacity(n), dtype=torch.uint8, device=dev)
@@ -99,7 +107,7 @@ def main():
         if distributed:
             # the path's one exchange: per-rank byte counts, then the blobs to rank 0 over xGMI
             total = int(meta[0].item())
-            res, _ = gather_bitstreams(out, total, dst=gathered)
+            res, _ = gather_bitstreams(out[:total].cpu() if rehearsal else out, total, dst=gathered)
             if rank == 0:
                 gathered = res if gathered is None or gathered.numel() < res.numel() else gathered
 
@@ -120,7 +128,7 @@ def main():
     launches, kernel_ms = enc.profile_read()
     enc.profile(False)
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -134,6 +142,12 @@ def main():
         want, wsz = orc.encode_frames(host, 2, W, H, first, qf, orc.MODE_FULL)
         got = out[:len(want)].cpu().numpy().tobytes()
         verified = got == want
+        if distributed and gathered is not None:
+            # the gathered stream continues with rank 1's frames (global indices n, n+1): check the seam
+            host1 = orc.synth_frames(2, W, H, seed=seed, first_index=n)
+            want1, _ = orc.encode_frames(host1, 2, W, H, n, qf, orc.MODE_FULL)
+            seam = gathered[total_bytes:total_bytes + len(want1)].cpu().numpy().tobytes()
+            verified = verified and seam == want1
 
         ms_per_step = elapsed / args.steps * 1e3
         fps = world * n * args.steps / elapsed
