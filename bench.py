@@ -96,23 +96,52 @@ def main():
     enc = Mpeg1Encoder(W, H, qf, "full", max_frames=n, device=gpu_index)
     first = rank * n  # global frame index of this rank's first frame
     rgb = enc.synth(n, seed=seed, first_frame_index=first, device=dev)
-    out = torch.empty(enc.default_out_capacity(n), dtype=torch.uint8, device=dev)
+    # two output buffers: for N > 1 the gather of step k overlaps the encode of step k+1
+    outs = [torch.empty(enc.default_out_capacity(n), dtype=torch.uint8, device=dev) for _ in range(2 if distributed else 1)]
+    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in outs]
     sizes = torch.empty(n, dtype=torch.int64, device=dev)
-    meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    out, meta = outs[0], metas[0]
     gathered = None
+    comm_stream = torch.cuda.Stream(device=dev) if distributed else None
+    encoded = [torch.cuda.Event() for _ in outs]      # encode into buffer b finished
+    drained = [None for _ in outs]                     # gather out of buffer b finished
+    pending = []                                       # buffers encoded but not yet gathered
+    step_no = 0
 
-    def step():
+    def gather_one(b):
+        """The path's one exchange, on the side stream: per-rank byte counts, then the blobs to rank 0 over xGMI."""
         nonlocal gathered
-        enc.encode(rgb, first, out=out, sizes=sizes, meta=meta)
-        if distributed:
-            # the path's one exchange: per-rank byte counts, then the blobs to rank 0 over xGMI
-            total = int(meta[0].item())
-            res, _ = gather_bitstreams(out[:total].cpu() if rehearsal else out, total, dst=gathered)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(encoded[b])
+            total = int(metas[b][0].item())
+            res, _ = gather_bitstreams(outs[b][:total].cpu() if rehearsal else outs[b], total, dst=gathered)
             if rank == 0:
                 gathered = res if gathered is None or gathered.numel() < res.numel() else gathered
+            ev = torch.cuda.Event()
+            ev.record(comm_stream)
+            drained[b] = ev
+
+    def step():
+        nonlocal step_no
+        b = step_no % len(outs)
+        step_no += 1
+        if distributed and drained[b] is not None:
+            torch.cuda.current_stream().wait_event(drained[b])   # buffer b is free again
+        enc.encode(rgb, first, out=outs[b], sizes=sizes, meta=metas[b])
+        if distributed:
+            encoded[b].record(torch.cuda.current_stream())
+            pending.append(b)
+            if len(pending) > 1:                                  # gather lags one step behind the encode
+                gather_one(pending.pop(0))
+
+    def drain():
+        while pending:
+            gather_one(pending.pop(0))
 
     def fence():
         if distributed:
+            drain()
+            torch.cuda.synchronize(dev)
             dist.barrier()
         torch.cuda.synchronize(dev)
 
