@@ -1086,6 +1086,10 @@ struct DenseGatherArgs {
     int first_index;
 };
 
+#ifndef M1V_GATHER_THREADS
+#define M1V_GATHER_THREADS 64
+#endif
+constexpr int kGatherThreads = M1V_GATHER_THREADS;
 __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
     const DenseGeom &d = a.d;
     int s = blockIdx.x, f = blockIdx.y;
@@ -1340,14 +1344,23 @@ struct m1v_encoder {
     bool narrow;       // no AC level can reach +-128: one byte per staged level
     int dense_T, runs_per_frame;
     uint32_t run_cap;
-    uint32_t *d_run_meta;
-    size_t scratch_bytes;
+    size_t scratch_bytes;   // per batch state
+    bool pipelined;         // layout + gather of batch k on `side` while batch k+1 encodes on the caller's stream
+    unsigned calls;
+    hipStream_t side;
     bool fast_ok;      // geometry allows the 4-byte-aligned 24-byte row loads
     Tables *d_tab;
-    uint8_t *d_scratch;
-    uint32_t *d_strip_bytes, *d_strip_off;
-    unsigned long long *d_frame_size, *d_frame_off;
-    uint32_t *d_status;
+    // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
+    // pipelined mode batch k+1 can encode while batch k is still being gathered.
+    struct Batch {
+        uint8_t *scratch;
+        uint32_t *run_meta;
+        uint32_t *strip_bytes, *strip_off;
+        unsigned long long *frame_size, *frame_off;
+        uint32_t *status;
+        hipEvent_t enc_done, gather_done;
+        bool gather_pending;
+    } batch[2];
     unsigned long long *d_stamps;
     // profiling
     bool prof;
@@ -1399,18 +1412,32 @@ static int configure_path(m1v_encoder *e, int dense_T) {
     } else {
         need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
     }
-    if (need > e->scratch_bytes) {
-        (void)hipFree(e->d_scratch);
-        e->d_scratch = nullptr;
-        e->scratch_bytes = 0;
-        if (hipMalloc(&e->d_scratch, need) != hipSuccess) return fail(M1V_E_HIP, "scratch allocation failed%s");
-        e->scratch_bytes = need;
+    const int sets = e->pipelined ? 2 : 1;
+    for (int i = 0; i < sets; i++) {
+        m1v_encoder::Batch &bt = e->batch[i];
+        if (need > e->scratch_bytes || !bt.scratch) {
+            (void)hipFree(bt.scratch);
+            bt.scratch = nullptr;
+            if (hipMalloc(&bt.scratch, need) != hipSuccess) return fail(M1V_E_HIP, "scratch allocation failed%s");
+        }
+        if (meta) {
+            (void)hipFree(bt.run_meta);
+            bt.run_meta = nullptr;
+            if (hipMalloc(&bt.run_meta, meta) != hipSuccess) return fail(M1V_E_HIP, "metadata allocation failed%s");
+        }
+        size_t nslots = (size_t)e->max_frames * g.n_strips;
+        if (!bt.strip_bytes) {
+            hipError_t err = hipMalloc(&bt.strip_bytes, nslots * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.strip_off, nslots * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
+            if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
+            if (err == hipSuccess) err = hipMalloc(&bt.status, sizeof(uint32_t));
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.gather_done, hipEventDisableTiming);
+            if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
+        }
     }
-    if (meta) {
-        (void)hipFree(e->d_run_meta);
-        e->d_run_meta = nullptr;
-        if (hipMalloc(&e->d_run_meta, meta) != hipSuccess) return fail(M1V_E_HIP, "metadata allocation failed%s");
-    }
+    if (need > e->scratch_bytes) e->scratch_bytes = need;
     return M1V_OK;
 }
 
@@ -1448,9 +1475,11 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->lds_words = 0;                 // 0 = default of the kernel in use
     e->dense = bps >= kWave;
     e->dense_T = 0;
-    e->d_run_meta = nullptr;
-    e->d_scratch = nullptr;
     e->scratch_bytes = 0;
+    e->pipelined = false;
+    e->calls = 0;
+    e->side = nullptr;
+    memset(e->batch, 0, sizeof e->batch);
     e->fast_ok = channels == 3 && (width % 8) == 0;
     e->prof = false;
     e->ev_used = 0;
@@ -1484,12 +1513,6 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
     if (err == hipSuccess) err = hipMemcpy(e->d_tab, t, sizeof(Tables), hipMemcpyHostToDevice);
     delete t;
-    size_t nslots = (size_t)max_frames * g.n_strips;
-    if (err == hipSuccess) err = hipMalloc(&e->d_strip_bytes, nslots * sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMalloc(&e->d_strip_off, nslots * sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMalloc(&e->d_frame_size, (size_t)max_frames * 8);
-    if (err == hipSuccess) err = hipMalloc(&e->d_frame_off, (size_t)max_frames * 8);
-    if (err == hipSuccess) err = hipMalloc(&e->d_status, sizeof(uint32_t));
 #ifdef M1V_STAMPS
     if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 16 * 8);
     if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
@@ -1514,14 +1537,19 @@ void m1v_destroy(m1v_encoder *e) {
     (void)hipSetDevice(e->device);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_tab);
-    (void)hipFree(e->d_scratch);
-    (void)hipFree(e->d_strip_bytes);
-    (void)hipFree(e->d_strip_off);
-    (void)hipFree(e->d_frame_size);
-    (void)hipFree(e->d_frame_off);
-    (void)hipFree(e->d_status);
+    for (m1v_encoder::Batch &bt : e->batch) {
+        (void)hipFree(bt.scratch);
+        (void)hipFree(bt.run_meta);
+        (void)hipFree(bt.strip_bytes);
+        (void)hipFree(bt.strip_off);
+        (void)hipFree(bt.frame_size);
+        (void)hipFree(bt.frame_off);
+        (void)hipFree(bt.status);
+        if (bt.enc_done) (void)hipEventDestroy(bt.enc_done);
+        if (bt.gather_done) (void)hipEventDestroy(bt.gather_done);
+    }
+    if (e->side) (void)hipStreamDestroy(e->side);
     (void)hipFree(e->d_stamps);
-    (void)hipFree(e->d_run_meta);
     delete e;
 }
 
@@ -1538,6 +1566,28 @@ size_t m1v_frame_bound(const m1v_encoder *e) {
 int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
     e->lds_words = words > 0 ? (words < 4 ? 4 : words) : 0;
+    return M1V_OK;
+}
+
+int m1v_set_pipelined(m1v_encoder *e, int enable) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (m1v_encoder::Batch &bt : e->batch) bt.gather_pending = false;
+    e->pipelined = enable != 0;
+    e->calls = 0;
+    if (e->pipelined && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    return configure_path(e, e->dense_T);
+}
+
+int m1v_flush(m1v_encoder *e, void *stream) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    HIP_TRY(hipSetDevice(e->device));
+    for (m1v_encoder::Batch &bt : e->batch)
+        if (bt.gather_pending) {
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, bt.gather_done, 0));
+            bt.gather_pending = false;
+        }
     return M1V_OK;
 }
 
@@ -1606,7 +1656,13 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     if (n_frames < 0 || n_frames > e->max_frames) return fail(M1V_E_ARG, "n_frames exceeds max_frames%s");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemsetAsync(e->d_status, 0, sizeof(uint32_t), st));
+    m1v_encoder::Batch &bt = e->batch[e->pipelined ? (e->calls++ & 1u) : 0];
+    hipStream_t gs = e->pipelined ? e->side : st;   // stream of the layout + gather kernels
+    if (e->pipelined && bt.gather_pending) {         // this set's previous gather must have drained its scratch
+        HIP_TRY(hipStreamWaitEvent(st, bt.gather_done, 0));
+        bt.gather_pending = false;
+    }
+    HIP_TRY(hipMemsetAsync(bt.status, 0, sizeof(uint32_t), st));
     if (n_frames == 0) {
         if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, 4, st));
@@ -1615,10 +1671,10 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     const Geometry &g = e->g;
     const bool fast = fast_path(e, d_rgb);
     LayoutArgs l;
-    l.strip_bytes = e->d_strip_bytes;
-    l.strip_off = e->d_strip_off;
-    l.frame_size = e->d_frame_size;
-    l.frame_off = e->d_frame_off;
+    l.strip_bytes = bt.strip_bytes;
+    l.strip_off = bt.strip_off;
+    l.frame_size = bt.frame_size;
+    l.frame_off = bt.frame_off;
     l.out_frame_sizes = (unsigned long long *)d_frame_sizes;
     l.out_total = (unsigned long long *)d_total;
     l.n_frames = n_frames;
@@ -1629,9 +1685,9 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.g = g;
         a.rgb = d_rgb;
         a.tab = e->d_tab;
-        a.scratch = e->d_scratch;
-        a.run_meta = e->d_run_meta;
-        a.status = e->d_status;
+        a.scratch = bt.scratch;
+        a.run_meta = bt.run_meta;
+        a.status = bt.status;
         a.n_frames = n_frames;
         a.threads = e->dense_T;
         a.runs_per_frame = e->runs_per_frame;
@@ -1656,6 +1712,10 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             hipLaunchKernelGGL((k_encode_dense<false, false>), grid, block, lds, st, a);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         HIP_TRY(hipGetLastError());
+        if (e->pipelined) {
+            HIP_TRY(hipEventRecord(bt.enc_done, st));
+            HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
+        }
 
         DenseGeom d;
         d.n_frames = n_frames;
@@ -1665,33 +1725,33 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.runs_per_frame = e->runs_per_frame;
         d.run_cap = e->run_cap;
         int total_strips = n_frames * g.n_strips;
-        hipLaunchKernelGGL(k_dense_strip_bytes, dim3((total_strips + 255) / 256), dim3(256), 0, st, d, e->d_run_meta,
-                           e->d_strip_bytes);
-        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, st, l);
-        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, st, l);
+        hipLaunchKernelGGL(k_dense_strip_bytes, dim3((total_strips + 255) / 256), dim3(256), 0, gs, d, bt.run_meta,
+                           bt.strip_bytes);
+        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, gs, l);
+        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
         DenseGatherArgs ga;
         ga.d = d;
-        ga.scratch = e->d_scratch;
-        ga.run_meta = e->d_run_meta;
-        ga.strip_bytes = e->d_strip_bytes;
-        ga.strip_off = e->d_strip_off;
-        ga.frame_size = e->d_frame_size;
-        ga.frame_off = e->d_frame_off;
+        ga.scratch = bt.scratch;
+        ga.run_meta = bt.run_meta;
+        ga.strip_bytes = bt.strip_bytes;
+        ga.strip_off = bt.strip_off;
+        ga.frame_size = bt.frame_size;
+        ga.frame_off = bt.frame_off;
         ga.tab = e->d_tab;
         ga.out = d_out;
         ga.out_cap = out_cap;
-        ga.status = e->d_status;
+        ga.status = bt.status;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather_dense, dim3(g.n_strips, n_frames), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(k_gather_dense, dim3(g.n_strips, n_frames), dim3(kGatherThreads), 0, gs, ga);
         HIP_TRY(hipGetLastError());
     } else {
         EncodeArgs a;
         a.g = g;
         a.rgb = d_rgb;
         a.tab = e->d_tab;
-        a.scratch = e->d_scratch;
-        a.strip_bytes = e->d_strip_bytes;
-        a.status = e->d_status;
+        a.scratch = bt.scratch;
+        a.strip_bytes = bt.strip_bytes;
+        a.status = bt.status;
         a.n_frames = n_frames;
         a.threads = e->threads;
         a.lds_words = e->lds_words > 0 ? e->lds_words : kDefaultLdsWords;
@@ -1705,27 +1765,35 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             hipLaunchKernelGGL(k_encode_strips<false>, grid, block, lds, st, a);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, st, l);
-        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, st, l);
+        if (e->pipelined) {
+            HIP_TRY(hipEventRecord(bt.enc_done, st));
+            HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
+        }
+        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, gs, l);
+        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
         GatherArgs ga;
-        ga.scratch = e->d_scratch;
-        ga.strip_bytes = e->d_strip_bytes;
-        ga.strip_off = e->d_strip_off;
-        ga.frame_size = e->d_frame_size;
-        ga.frame_off = e->d_frame_off;
+        ga.scratch = bt.scratch;
+        ga.strip_bytes = bt.strip_bytes;
+        ga.strip_off = bt.strip_off;
+        ga.frame_size = bt.frame_size;
+        ga.frame_off = bt.frame_off;
         ga.tab = e->d_tab;
         ga.out = d_out;
         ga.out_cap = out_cap;
-        ga.status = e->d_status;
+        ga.status = bt.status;
         ga.strip_cap = g.strip_cap;
         ga.n_frames = n_frames;
         ga.n_strips = g.n_strips;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, gs, ga);
         HIP_TRY(hipGetLastError());
     }
     if (d_status)
-        HIP_TRY(hipMemcpyAsync(d_status, e->d_status, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_status, bt.status, sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
+    if (e->pipelined) {
+        HIP_TRY(hipEventRecord(bt.gather_done, gs));
+        bt.gather_pending = true;
+    }
     return M1V_OK;
 }
 
@@ -1754,6 +1822,7 @@ long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first
             err = hipErrorUnknown;
         }
     }
+    if (err == hipSuccess && m1v_flush(e, nullptr) != M1V_OK) err = hipErrorUnknown;
     if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err == hipSuccess) {
         std::vector<unsigned long long> meta((size_t)n_frames + 2);

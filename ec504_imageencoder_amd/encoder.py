@@ -78,6 +78,21 @@ class Mpeg1Encoder:
             raise EncoderError(rc, "m1v_encode_device")
         return out, sizes, meta
 
+    def set_pipelined(self, enable=True):
+        """Overlap each batch's layout + gather (internal stream) with the next batch's encode kernel.
+        Outputs of a batch are complete only behind flush(); callers double-buffer `out`."""
+        rc = _ffi.lib().m1v_set_pipelined(self._h, 1 if enable else 0)
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_set_pipelined")
+
+    def flush(self, stream=None):
+        """Make `stream` (torch stream, default: the current one) wait for all pending gathers."""
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream()
+        rc = _ffi.lib().m1v_flush(self._h, C.c_void_p(st.cuda_stream))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_flush")
+
     def default_out_capacity(self, n):
         # typical output is far below the worst-case bound; callers that need the guarantee pass
         # `out` of frame_bound * n bytes.  NOSPACE is reported through the status word.
@@ -87,6 +102,7 @@ class Mpeg1Encoder:
         """Synchronous convenience: returns (bytes, [sizes])."""
         import torch
         out, sizes, meta = self.encode(rgb, first_frame_index)
+        self.flush()
         torch.cuda.synchronize(rgb.device)
         total, status = (int(x) for x in meta.cpu())
         status &= 0xFFFFFFFF
@@ -100,6 +116,7 @@ class Mpeg1Encoder:
     def _retry_bytes(self, rgb, first_frame_index, out):
         import torch
         out, sizes, meta = self.encode(rgb, first_frame_index, out=out)
+        self.flush()
         torch.cuda.synchronize(rgb.device)
         total, status = (int(x) for x in meta.cpu())
         if status & 0xFFFFFFFF:

@@ -15,6 +15,7 @@
  *       image_processing.c:400, encode_blk_coeff source/vlc.c:315, bit_vector.c appends),
  *       the strip zero-padding (encoder.h:442), the 16-bit length back-patch (encoder.h:448-453)
  *       and the 4 trailing bytes (encoder.h:456-458).
+ *   m1v_set_pipelined / m1v_flush   no reference counterpart: overlap of one batch's gather with the next encode
  *   m1v_coefficients_device    fast_DCT + quantization + zigzag_scanning only (BASELINE config 2)
  *   m1v_convert_device/_host   convert_rgb_to_ycbcr, image_processing.c:68-110 (feeds the .bit files,
  *                              write_to_bitstream image_processing.c:753)
@@ -86,6 +87,15 @@ size_t m1v_file_prolog(uint8_t out[27]);
 int m1v_encode_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int first_frame_index,
                       uint8_t *d_out, size_t out_cap, uint64_t *d_frame_sizes, uint64_t *d_total,
                       uint32_t *d_status, void *stream);
+
+/* Pipelined mode (off by default).  When on, m1v_encode_device launches only the encode kernel on `stream`;
+ * the layout scans and the gather into d_out run on an internal stream, so the NEXT batch's encode kernel
+ * (launched on `stream`) overlaps them.  d_out / d_frame_sizes / d_total / d_status of a batch are complete
+ * once work enqueued behind m1v_flush(enc, s) on stream s has started; callers double-buffer d_out.  The
+ * internal scratch is double-buffered, so at most two batches are in flight. */
+int m1v_set_pipelined(m1v_encoder *enc, int enable);
+/* Makes `stream` wait for every gather still pending on the internal stream. */
+int m1v_flush(m1v_encoder *enc, void *stream);
 
 /* Host-buffer convenience (PCIe inclusive, synchronous): returns total bytes or negative M1V_E_*. */
 long m1v_encode_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,

@@ -289,6 +289,34 @@ def test_dense_run_lengths(torch_cuda, orc, threads):
     enc.close()
 
 
+def test_pipelined_mode_matches(torch_cuda, orc):
+    """Pipelined mode: layout + gather of batch k on the internal stream while batch k+1 encodes.  Six batches of
+    different frames back to back, outputs double-buffered by the caller, one flush at the end: every batch's
+    bytes, sizes, totals and status equal the oracle's."""
+    torch = torch_cuda
+    W, H, n = 704, 576, 6
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    enc.set_pipelined(True)
+    batches = [enc.synth(n, seed=1000 + k) for k in range(6)]
+    outs = [torch.empty(enc.default_out_capacity(n), dtype=torch.uint8, device="cuda") for _ in range(6)]
+    res = []
+    for k, rgb in enumerate(batches):
+        res.append(enc.encode(rgb, first_frame_index=10 * k, out=outs[k]))
+    enc.flush()
+    torch.cuda.synchronize()
+    for k, (out, sizes, meta) in enumerate(res):
+        want, wsizes = orc.encode_frames(batches[k].cpu().numpy(), n, W, H, 10 * k, 12, orc.MODE_FULL, threads=8)
+        total, status = (int(x) for x in meta.cpu())
+        assert status & 0xFFFFFFFF == 0 and total == len(want), k
+        assert out[:total].cpu().numpy().tobytes() == want, k
+        assert [int(x) for x in sizes[:n].cpu()] == [int(x) for x in wsizes], k
+    # switching back restores the plain stream-ordered behaviour
+    enc.set_pipelined(False)
+    got, _ = enc.encode_to_bytes(batches[0], 0)
+    assert got == orc.encode_frames(batches[0].cpu().numpy(), n, W, H, 0, 12, orc.MODE_FULL, threads=8)[0]
+    enc.close()
+
+
 def test_unencodable_level_is_reported(torch_cuda, orc):
     """|level| >= 256 with run >= 1: the reference dereferences NULL (vlc.c:349 -> bit_vector.c:100).
     The HIP path reports M1V_E_UNENCODABLE instead of producing bytes; the oracle flags the same input."""
