@@ -166,10 +166,11 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     }
     const size_t frame_in = m1v_frame_bytes_in(enc), bound = m1v_frame_bound(enc);
     const int write_bit = env_int("EC504_WRITE_BIT", 1);
-    batch_in = (uint8_t *)malloc(frame_in * (size_t)batch);
-    batch_out = (uint8_t *)malloc(bound * (size_t)batch);
+    /* pinned staging: the copies to and from the GPU then run at the PCIe rate */
+    batch_in = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
+    batch_out = (uint8_t *)m1v_alloc_host(bound * (size_t)batch);
     sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
-    if (write_bit) planes = (uint8_t *)malloc((size_t)W * H * 3 * (size_t)batch);
+    if (write_bit) planes = (uint8_t *)m1v_alloc_host((size_t)W * H * 3 * (size_t)batch);
     if (!batch_in || !batch_out || !sizes || (write_bit && !planes)) {
         printf("Error: Memory allocation failed.\n");
         goto done;
@@ -197,10 +198,10 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     rc = 0;
 
 done:
-    free(batch_in);
-    free(batch_out);
+    m1v_free_host(batch_in);
+    m1v_free_host(batch_out);
     free(sizes);
-    free(planes);
+    m1v_free_host(planes);
     m1v_destroy(enc);
     release_images(&imgs);
     fclose(fp);

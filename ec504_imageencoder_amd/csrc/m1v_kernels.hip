@@ -181,18 +181,19 @@ __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
 // Otherwise (x within 3.6e-4 of an integer: < 0.1 % of pixels, among them exactly the ties where fp64
 // rounding decides the byte) the lane re-evaluates the reference's fp64 expression.
 // tests: all 2^24 triples x 3 components on the GPU.
-// One pixel through the fast path; `bad` tells the caller to redo it with component_fp64.
-__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, bool &bad) {
+// One pixel through the fast path; `h` = fract of the fp32 value (the caller decides on it).
+__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, float &h) {
     float t = fmaf((float)b, k.kb, k.k0);
     t = fmaf((float)g, k.kg, t);
     t = fmaf((float)r, k.kr, t);
-    bad = !(__builtin_amdgcn_fractf(t) <= 1.0f - 2.0f * kEps);
+    h = __builtin_amdgcn_fractf(t);
     return (int)t;
 }
+constexpr float kFractLimit = 1.0f - 2.0f * kEps;
 __device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
-    bool bad;
-    int q = component_fast(r, g, b, k, bad);
-    if (bad) {
+    float h;
+    int q = component_fast(r, g, b, k, h);
+    if (!(h <= kFractLimit)) {
         CompCoef d = comp_coef(k.comp);
         q = component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
     }
@@ -212,10 +213,15 @@ __device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k
         int byte = 3 * j + ch;
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
+    // per-pixel flags live in scalar registers (compare results); keeping the eight fract values in VGPRs
+    // instead (one v_max per pixel, one compare per row) measured +1 % but tips the kernel over its 96-VGPR
+    // budget in some builds (168 B/lane of scratch = 1.7x slower), so the robust form is used
     bool bad[8], any = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, bad[j]);
+        float h;
+        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, h);
+        bad[j] = !(h <= kFractLimit);
         any |= bad[j];
     }
     if (any) {
@@ -572,9 +578,12 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
         if (i == 0) dc = q[0];
         if (STAGE8) {
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-                stage[(h * 8 + i) * T + tid] = ((uint32_t)q[4 * h] & 0xffu) | (((uint32_t)q[4 * h + 1] & 0xffu) << 8) |
-                                               (((uint32_t)q[4 * h + 2] & 0xffu) << 16) | ((uint32_t)q[4 * h + 3] << 24);
+            for (int h = 0; h < 2; h++) {
+                // low bytes of four levels -> one word: two v_perm_b32 and an OR
+                uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * h + 1], (uint32_t)q[4 * h], 0x0c0c0400u);
+                uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * h + 3], (uint32_t)q[4 * h + 2], 0x04000c0cu);
+                stage[(h * 8 + i) * T + tid] = lo | hi;
+            }
         } else {
 #pragma unroll
             for (int h = 0; h < 4; h++)
@@ -1362,11 +1371,28 @@ struct m1v_encoder {
         bool gather_pending;
     } batch[2];
     unsigned long long *d_stamps;
+    // device-side staging of the host-buffer entry points, kept between calls
+    struct HostPath {
+        uint8_t *d_in, *d_out, *d_planes;
+        unsigned long long *d_meta;
+        size_t in_cap, out_cap, planes_cap, meta_cap;
+    } hp;
     // profiling
     bool prof;
     std::vector<hipEvent_t> ev;
     size_t ev_used;
 };
+
+template <typename T>
+static hipError_t ensure_device(T **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t err = hipMalloc(p, need);
+    if (err == hipSuccess) *cap = need;
+    return err;
+}
 
 extern "C" {
 
@@ -1480,6 +1506,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->calls = 0;
     e->side = nullptr;
     memset(e->batch, 0, sizeof e->batch);
+    memset(&e->hp, 0, sizeof e->hp);
     e->fast_ok = channels == 3 && (width % 8) == 0;
     e->prof = false;
     e->ev_used = 0;
@@ -1549,6 +1576,10 @@ void m1v_destroy(m1v_encoder *e) {
         if (bt.gather_done) (void)hipEventDestroy(bt.gather_done);
     }
     if (e->side) (void)hipStreamDestroy(e->side);
+    (void)hipFree(e->hp.d_in);
+    (void)hipFree(e->hp.d_out);
+    (void)hipFree(e->hp.d_planes);
+    (void)hipFree(e->hp.d_meta);
     (void)hipFree(e->d_stamps);
     delete e;
 }
@@ -1797,6 +1828,17 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     return M1V_OK;
 }
 
+/* Pinned host memory for callers of the host-buffer entry points: H2D/D2H copies from it run at the PCIe
+ * rate instead of being staged by the runtime. */
+void *m1v_alloc_host(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void m1v_free_host(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first_frame_index,
                      uint8_t *out, size_t out_cap, uint64_t *frame_sizes) {
     if (!e || !rgb || !out) return fail(M1V_E_ARG, "null pointer%s");
@@ -1806,49 +1848,27 @@ long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first
     size_t in_bytes = (size_t)e->g.frame_bytes * n_frames;
     size_t bound = m1v_frame_bound(e) * (size_t)n_frames;
     size_t dcap = out_cap < bound ? out_cap : bound;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    unsigned long long *d_meta = nullptr; // [n_frames] sizes, [1] total, then status
-    long rc = M1V_E_HIP;
-    hipError_t err = hipMalloc(&d_in, in_bytes);
-    if (err == hipSuccess) err = hipMalloc(&d_out, dcap);
-    if (err == hipSuccess) err = hipMalloc(&d_meta, (size_t)(n_frames + 2) * 8);
-    if (err == hipSuccess) err = hipMemcpy(d_in, rgb, in_bytes, hipMemcpyHostToDevice);
-    if (err == hipSuccess) {
-        int r = m1v_encode_device(e, d_in, n_frames, first_frame_index, d_out, dcap,
-                                  (uint64_t *)d_meta, (uint64_t *)(d_meta + n_frames),
-                                  (uint32_t *)(d_meta + n_frames + 1), nullptr);
-        if (r != M1V_OK) {
-            rc = r;
-            err = hipErrorUnknown;
-        }
-    }
-    if (err == hipSuccess && m1v_flush(e, nullptr) != M1V_OK) err = hipErrorUnknown;
-    if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
-    if (err == hipSuccess) {
-        std::vector<unsigned long long> meta((size_t)n_frames + 2);
-        err = hipMemcpy(meta.data(), d_meta, meta.size() * 8, hipMemcpyDeviceToHost);
-        if (err == hipSuccess) {
-            uint32_t status = (uint32_t)meta[(size_t)n_frames + 1];
-            unsigned long long total = meta[n_frames];
-            if (status & M1V_STATUS_UNENCODABLE) {
-                rc = fail(M1V_E_UNENCODABLE, "an AC level has |level| >= 256 (the reference crashes here)%s");
-            } else if ((status & M1V_STATUS_NOSPACE) || total > out_cap) {
-                rc = fail(M1V_E_NOSPACE, "output buffer too small%s");
-            } else {
-                err = hipMemcpy(out, d_out, total, hipMemcpyDeviceToHost);
-                if (err == hipSuccess) {
-                    if (frame_sizes)
-                        for (int f = 0; f < n_frames; f++) frame_sizes[f] = meta[f];
-                    rc = (long)total;
-                }
-            }
-        }
-    }
-    if (err != hipSuccess && rc == M1V_E_HIP) fail(M1V_E_HIP, "HIP: %s", hipGetErrorString(err));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    (void)hipFree(d_meta);
-    return rc;
+    m1v_encoder::HostPath &hp = e->hp;
+    HIP_TRY(ensure_device(&hp.d_in, &hp.in_cap, in_bytes));
+    HIP_TRY(ensure_device(&hp.d_out, &hp.out_cap, dcap));
+    HIP_TRY(ensure_device(&hp.d_meta, &hp.meta_cap, (size_t)(n_frames + 2) * 8)); // [n] sizes, total, status
+    HIP_TRY(hipMemcpy(hp.d_in, rgb, in_bytes, hipMemcpyHostToDevice));
+    int r = m1v_encode_device(e, hp.d_in, n_frames, first_frame_index, hp.d_out, dcap, (uint64_t *)hp.d_meta,
+                              (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), nullptr);
+    if (r != M1V_OK) return r;
+    if (m1v_flush(e, nullptr) != M1V_OK) return M1V_E_HIP;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    std::vector<unsigned long long> meta((size_t)n_frames + 2);
+    HIP_TRY(hipMemcpy(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost));
+    uint32_t status = (uint32_t)meta[(size_t)n_frames + 1];
+    unsigned long long total = meta[n_frames];
+    if (status & M1V_STATUS_UNENCODABLE)
+        return fail(M1V_E_UNENCODABLE, "an AC level has |level| >= 256 (the reference crashes here)%s");
+    if ((status & M1V_STATUS_NOSPACE) || total > out_cap) return fail(M1V_E_NOSPACE, "output buffer too small%s");
+    HIP_TRY(hipMemcpy(out, hp.d_out, total, hipMemcpyDeviceToHost));
+    if (frame_sizes)
+        for (int f = 0; f < n_frames; f++) frame_sizes[f] = meta[f];
+    return (long)total;
 }
 
 int m1v_coefficients_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int16_t *d_coeffs,
@@ -1892,17 +1912,14 @@ int m1v_convert_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, uint8_t *
     HIP_TRY(hipSetDevice(e->device));
     size_t in_bytes = (size_t)e->g.frame_bytes * n_frames;
     size_t out_bytes = (size_t)e->g.W * e->g.H * 3 * n_frames;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    hipError_t err = hipMalloc(&d_in, in_bytes);
-    if (err == hipSuccess) err = hipMalloc(&d_out, out_bytes);
-    if (err == hipSuccess) err = hipMemcpy(d_in, rgb, in_bytes, hipMemcpyHostToDevice);
-    int rc = M1V_OK;
-    if (err == hipSuccess) rc = m1v_convert_device(e, d_in, n_frames, d_out, nullptr);
-    if (err == hipSuccess && rc == M1V_OK) err = hipMemcpy(planes, d_out, out_bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    if (err != hipSuccess) return fail(M1V_E_HIP, "HIP: %s", hipGetErrorString(err));
-    return rc;
+    m1v_encoder::HostPath &hp = e->hp;
+    HIP_TRY(ensure_device(&hp.d_in, &hp.in_cap, in_bytes));
+    HIP_TRY(ensure_device(&hp.d_planes, &hp.planes_cap, out_bytes));
+    HIP_TRY(hipMemcpy(hp.d_in, rgb, in_bytes, hipMemcpyHostToDevice));
+    int rc = m1v_convert_device(e, hp.d_in, n_frames, hp.d_planes, nullptr);
+    if (rc != M1V_OK) return rc;
+    HIP_TRY(hipMemcpy(planes, hp.d_planes, out_bytes, hipMemcpyDeviceToHost));
+    return M1V_OK;
 }
 
 int m1v_subsample_device(m1v_encoder *e, const uint8_t *d_cb, const uint8_t *d_cr, uint8_t *d_cb_sub,

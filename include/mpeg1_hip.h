@@ -101,6 +101,11 @@ int m1v_flush(m1v_encoder *enc, void *stream);
 long m1v_encode_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,
                      uint8_t *out, size_t out_cap, uint64_t *frame_sizes);
 
+/* Pinned host memory for the buffers handed to the *_host entry points (optional; any host pointer works, pinned
+ * ones are copied at the PCIe rate). */
+void *m1v_alloc_host(size_t bytes);
+void m1v_free_host(void *p);
+
 /* The 64 zigzag-ordered quantised levels of every visited block, int16, in emission order
  * [frame][strip][macroblock][Y0 Y1 Y2 Y3 Cb Cr][64]. */
 int m1v_coefficients_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int16_t *d_coeffs,

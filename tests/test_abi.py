@@ -75,3 +75,47 @@ def test_device_code_is_gfx950_and_unfused(built):
     asm = out.stdout
     assert "v_mul_f64" in asm and "v_add_f64" in asm
     assert not re.search(r"v_fma(c)?_f64", asm), "fp64 FMA found: colour conversion would not be bit-exact"
+
+
+def test_encode_kernels_do_not_spill(built):
+    """The dominant kernel is latency/issue bound at 5 waves per SIMD: its speed hinges on fitting 96 VGPRs with
+    no scratch (a build that spilled 168 B/lane measured 1.7x slower).  Read the code object's metadata."""
+    readobj = "/opt/rocm/lib/llvm/bin/llvm-readobj"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "ec504_imageencoder_amd", "csrc", "m1v_kernels.o")
+    if not (os.path.exists(readobj) and os.path.exists(obj)):
+        pytest.skip("llvm tools or object absent")
+    import glob
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(obj, os.path.join(td, "k.o"))
+        subprocess.run([objdump, "--offloading", "k.o"], cwd=td, capture_output=True, text=True)
+        cos = glob.glob(os.path.join(td, "k.o.*gfx950*"))
+        if not cos:
+            pytest.skip("cannot extract the gfx950 code object")
+        notes = subprocess.run([readobj, "--notes", cos[0]], capture_output=True, text=True).stdout
+    kernels = {}
+    name = None
+    fields = {}
+    for line in notes.splitlines():
+        t = line.strip()
+        if t.startswith("- .") or t.startswith("-   ."):
+            if name:
+                kernels[name] = fields
+            name, fields = None, {}
+            t = t.lstrip("- ").strip()
+        m = re.match(r"\.(name|vgpr_count|private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count):\s*(\S+)", t)
+        if m:
+            if m.group(1) == "name":
+                name = m.group(2)
+            else:
+                fields[m.group(1)] = int(m.group(2))
+    if name:
+        kernels[name] = fields
+    dense = {k: v for k, v in kernels.items() if "k_encode_dense" in k}
+    assert len(dense) == 4, sorted(kernels)
+    for k, v in dense.items():
+        assert v.get("private_segment_fixed_size", 0) == 0, (k, v)
+        assert v.get("vgpr_spill_count", 0) == 0, (k, v)
+        assert v.get("vgpr_count", 999) <= 96, (k, v)
