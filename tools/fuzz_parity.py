@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Fuzz soak on the GPU: random geometry / quality / channels / mode / dense run length / LDS image size / content
+class, HIP stream vs oracle stream, byte for byte.  usage: fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import oracle_ffi as orc
+from ec504_imageencoder_amd import EncoderError, Mpeg1Encoder
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+
+
+def content(kind, n, H, W, C):
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind == "noise":
+        a = rng.integers(0, 256, (n, H, W, C), dtype=np.uint8)
+    elif kind == "extremes":
+        a = (rng.integers(0, 2, (n, H, W, C)) * 255).astype(np.uint8)
+    elif kind == "smooth":
+        base = (xx * 3 + yy * 2) % 256
+        a = np.clip(base[None, :, :, None] + rng.integers(-6, 7, (n, H, W, C)), 0, 255).astype(np.uint8)
+    elif kind == "blocks":
+        cell = int(rng.choice([2, 3, 4, 5, 8]))
+        v = rng.integers(0, 256, (n, (H + cell - 1) // cell, (W + cell - 1) // cell, C), dtype=np.uint8)
+        a = np.repeat(np.repeat(v, cell, 1), cell, 2)[:, :H, :W]
+    else:  # stripes: strong isolated coefficients
+        period = int(rng.choice([2, 3, 4, 6, 8, 16]))
+        s = ((xx // period + (yy // period) * int(rng.integers(0, 2))) % 2 * 255).astype(np.uint8)
+        a = np.broadcast_to(s[None, :, :, None], (n, H, W, C)).copy()
+        a ^= rng.integers(0, 8, a.shape, dtype=np.uint8)
+    return np.ascontiguousarray(a)
+
+
+t_end = time.time() + budget
+cases = fails = skipped = 0
+while time.time() < t_end:
+    mode = "full" if rng.random() < 0.8 else "strict"
+    W = int(rng.choice([16, 24, 96, 100, 176, 200, 352, 366, 640, 720, 1024, 1920]))
+    H = int(rng.choice([16, 40, 144, 150, 288, 300, 480, 576, 1088, 1504, 2304]))
+    if mode == "strict" and (W < 96 or H < 144):
+        continue
+    if W * H > 1920 * 1200:
+        continue
+    C = 3 if rng.random() < 0.85 else 4
+    qf = int(rng.choice([1, 5, 12, 12, 12, 25, 40, 50, 60, 75, 76, 77, 85, 92, 100]))
+    n = int(rng.integers(1, 5))
+    kind = str(rng.choice(["noise", "extremes", "smooth", "blocks", "stripes"]))
+    rgb = content(kind, n, H, W, C)
+    first = int(rng.integers(0, 600))
+    m = orc.MODE_FULL if mode == "full" else orc.MODE_STRICT
+    try:
+        want, wsizes = orc.encode_frames(rgb, n, W, H, first, qf, m, channels=C, threads=8)
+        expect_error = False
+    except ValueError:
+        expect_error = True
+    enc = Mpeg1Encoder(W, H, qf, mode, channels=C, max_frames=n)
+    bps = enc.mb_rows * 6
+    if bps >= 64 and rng.random() < 0.6:
+        choices = [t for t in (64, 128, 192, 256, 320, 384) if t <= bps]
+        enc.debug_set_dense_threads(int(rng.choice(choices)))
+    if rng.random() < 0.4:
+        enc.debug_set_lds_words(int(rng.choice([4, 16, 64, 256, 1024, 4096])))
+    if rng.random() < 0.3:
+        enc.set_pipelined(True)
+    desc = f"{W}x{H}x{C} {mode} qf{qf} n{n} {kind} first{first}"
+    try:
+        got, sizes = enc.encode_to_bytes(torch.from_numpy(rgb).cuda(), first)
+        if expect_error:
+            print("MISSED ERROR", desc); fails += 1
+        elif got != want or sizes != [int(x) for x in wsizes]:
+            print("MISMATCH", desc, len(got), len(want)); fails += 1
+    except EncoderError as e:
+        if not expect_error or e.code != -2:
+            print("UNEXPECTED ERROR", desc, e); fails += 1
+        else:
+            skipped += 1
+    enc.close()
+    cases += 1
+print(f"fuzz: {cases} cases, {skipped} expected-unencodable, {fails} failures")
+sys.exit(1 if fails else 0)
