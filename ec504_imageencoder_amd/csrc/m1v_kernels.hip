@@ -1071,22 +1071,64 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
     return m[1];
 }
 
-__global__ __launch_bounds__(256) void k_dense_strip_bytes(DenseGeom d, const uint32_t *run_meta,
-                                                           uint32_t *strip_bytes) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.n_frames * d.n_strips) return;
-    int f = i / d.n_strips, s = i - f * d.n_strips;
+// Per strip: where its segments live and how many bits each has, precomputed once so that the gather needs one
+// (scalar, workgroup-uniform) load instead of a chain of metadata loads and integer divisions.
+constexpr int kMaxSeg = 6;
+struct StripDesc {
+    uint32_t n;                 // number of segments, or ~0u: more than kMaxSeg (tiny run lengths) -> generic walk
+    uint32_t src_off[kMaxSeg];  // byte offset of the segment inside the frame's scratch area
+    uint32_t bits[kMaxSeg];
+    uint32_t pad[3];
+};
+
+// One workgroup per frame: segment bits -> strip descriptors and byte counts -> exclusive scan of the strips.
+__global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, const uint32_t *run_meta, uint32_t *strip_bytes,
+                                                            uint32_t *strip_off, StripDesc *desc,
+                                                            unsigned long long *frame_size) {
+    __shared__ uint32_t ws[32];
+    const int f = blockIdx.x;
     const uint32_t *mf = run_meta + (size_t)f * d.runs_per_frame * 4;
-    int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
-    uint32_t bits = 0, unused;
-    for (int w = w_lo; w <= w_hi; w++) bits += dense_segment(d, mf, w, s, unused);
-    strip_bytes[i] = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+    uint32_t run_total = 0;
+    for (int base = 0; base < d.n_strips; base += 256) {
+        const int s = base + threadIdx.x;
+        uint32_t nbytes = 0;
+        if (s < d.n_strips) {
+            const size_t i = (size_t)f * d.n_strips + s;
+            int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
+            uint32_t bits = 0;
+            StripDesc sd;
+            sd.n = (w_hi - w_lo + 1) <= kMaxSeg ? (uint32_t)(w_hi - w_lo + 1) : ~0u;
+#pragma unroll
+            for (int k = 0; k < kMaxSeg; k++) sd.src_off[k] = sd.bits[k] = 0;
+            sd.pad[0] = sd.pad[1] = sd.pad[2] = 0;
+            for (int w = w_lo; w <= w_hi; w++) {
+                uint32_t boff, L = dense_segment(d, mf, w, s, boff);
+                int k = w - w_lo;
+#pragma unroll
+                for (int kk = 0; kk < kMaxSeg; kk++)
+                    if (kk == k) {
+                        sd.src_off[kk] = (uint32_t)w * d.run_cap + boff;
+                        sd.bits[kk] = L;
+                    }
+                bits += L;
+            }
+            desc[i] = sd;
+            nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+            strip_bytes[i] = nbytes;
+        }
+        uint32_t tot;
+        uint32_t off = block_scan_exclusive(nbytes, ws, 256, tot);
+        if (s < d.n_strips) strip_off[(size_t)f * d.n_strips + s] = run_total + off;
+        run_total += tot;
+    }
+    if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
 }
 
 struct DenseGatherArgs {
     DenseGeom d;
     const uint8_t *scratch;
     const uint32_t *run_meta, *strip_bytes, *strip_off;
+    const StripDesc *desc;
     const unsigned long long *frame_size, *frame_off;
     const Tables *tab;
     uint8_t *out;
@@ -1094,6 +1136,19 @@ struct DenseGatherArgs {
     uint32_t *status;
     int first_index;
 };
+
+// 32 bits [lo_bit, lo_bit + 32) of a strip that is the concatenation of segments (src, bits): a 64-bit window of
+// the source segment (word loads from the word-aligned scratch), funnel-shifted to the destination phase.
+__device__ __forceinline__ uint32_t strip_bits_from(const uint8_t *seg_base, uint32_t D, uint32_t L, uint32_t lo_bit) {
+    uint32_t hi_bit = lo_bit + 32u;
+    uint32_t lo = max(lo_bit, D), hi = min(hi_bit, D + L);
+    if (lo >= hi) return 0u;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(seg_base);
+    uint32_t sb = lo - D, nb = hi - lo, wi = sb >> 5, sh = sb & 31u;
+    unsigned long long win = ((unsigned long long)__builtin_bswap32(src[wi]) << 32) | __builtin_bswap32(src[wi + 1]);
+    uint32_t bits = (uint32_t)((win << sh) >> (64u - nb));
+    return bits << (32u - (lo - lo_bit) - nb);
+}
 
 #ifndef M1V_GATHER_THREADS
 #define M1V_GATHER_THREADS 64
@@ -1108,27 +1163,28 @@ __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
         return;
     }
     size_t idx = (size_t)f * d.n_strips + s;
-    const uint32_t *mf = a.run_meta + (size_t)f * d.runs_per_frame * 4;
     const uint8_t *slots = a.scratch + (size_t)f * d.runs_per_frame * d.run_cap;
     uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
     uint32_t n = a.strip_bytes[idx];
-    int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
-    // every thread assembles 32 bits of the strip: a 64-bit window of the source segment (word loads from the
-    // word-aligned scratch), funnel-shifted to the destination phase
     const uint32_t nwords = (n + 3) >> 2;
+    const StripDesc sd = a.desc[idx]; // workgroup-uniform: scalar loads
     for (uint32_t j = threadIdx.x; j < nwords; j += blockDim.x) {
-        uint32_t lo_bit = 32u * j, hi_bit = lo_bit + 32u, val = 0, D = 0;
-        for (int w = w_lo; w <= w_hi; w++) {
-            uint32_t boff, L = dense_segment(d, mf, w, s, boff);
-            uint32_t lo = max(lo_bit, D), hi = min(hi_bit, D + L);
-            if (lo < hi) { // bits [lo, hi) of the strip come from bits [lo - D, hi - D) of this segment
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(slots + (size_t)w * d.run_cap + boff);
-                uint32_t sb = lo - D, nb = hi - lo, wi = sb >> 5, sh = sb & 31u;
-                unsigned long long win = ((unsigned long long)__builtin_bswap32(src[wi]) << 32) | __builtin_bswap32(src[wi + 1]);
-                uint32_t bits = (uint32_t)((win << sh) >> (64u - nb));
-                val |= bits << (32u - (lo - lo_bit) - nb);
+        uint32_t lo_bit = 32u * j, val = 0, D = 0;
+        if (sd.n != ~0u) {
+#pragma unroll
+            for (int k = 0; k < kMaxSeg; k++)
+                if ((uint32_t)k < sd.n) {
+                    val |= strip_bits_from(slots + sd.src_off[k], D, sd.bits[k], lo_bit);
+                    D += sd.bits[k];
+                }
+        } else { // many short runs per strip: walk the run metadata
+            const uint32_t *mf = a.run_meta + (size_t)f * d.runs_per_frame * 4;
+            int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
+            for (int w = w_lo; w <= w_hi; w++) {
+                uint32_t boff, L = dense_segment(d, mf, w, s, boff);
+                val |= strip_bits_from(slots + (size_t)w * d.run_cap + boff, D, L, lo_bit);
+                D += L;
             }
-            D += L;
         }
         uint32_t b0 = 4u * j;
         uint8_t *o = dst + b0;
@@ -1365,6 +1421,7 @@ struct m1v_encoder {
         uint8_t *scratch;
         uint32_t *run_meta;
         uint32_t *strip_bytes, *strip_off;
+        StripDesc *strip_desc;
         unsigned long long *frame_size, *frame_off;
         uint32_t *status;
         hipEvent_t enc_done, gather_done;
@@ -1455,6 +1512,7 @@ static int configure_path(m1v_encoder *e, int dense_T) {
         if (!bt.strip_bytes) {
             hipError_t err = hipMalloc(&bt.strip_bytes, nslots * sizeof(uint32_t));
             if (err == hipSuccess) err = hipMalloc(&bt.strip_off, nslots * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.strip_desc, nslots * sizeof(StripDesc));
             if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.status, sizeof(uint32_t));
@@ -1569,6 +1627,7 @@ void m1v_destroy(m1v_encoder *e) {
         (void)hipFree(bt.run_meta);
         (void)hipFree(bt.strip_bytes);
         (void)hipFree(bt.strip_off);
+        (void)hipFree(bt.strip_desc);
         (void)hipFree(bt.frame_size);
         (void)hipFree(bt.frame_off);
         (void)hipFree(bt.status);
@@ -1755,10 +1814,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.T = e->dense_T;
         d.runs_per_frame = e->runs_per_frame;
         d.run_cap = e->run_cap;
-        int total_strips = n_frames * g.n_strips;
-        hipLaunchKernelGGL(k_dense_strip_bytes, dim3((total_strips + 255) / 256), dim3(256), 0, gs, d, bt.run_meta,
-                           bt.strip_bytes);
-        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, gs, l);
+        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.run_meta, bt.strip_bytes,
+                           bt.strip_off, bt.strip_desc, bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
         DenseGatherArgs ga;
         ga.d = d;
@@ -1766,6 +1823,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.run_meta = bt.run_meta;
         ga.strip_bytes = bt.strip_bytes;
         ga.strip_off = bt.strip_off;
+        ga.desc = bt.strip_desc;
         ga.frame_size = bt.frame_size;
         ga.frame_off = bt.frame_off;
         ga.tab = e->d_tab;
