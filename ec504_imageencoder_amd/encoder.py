@@ -202,3 +202,50 @@ def file_prolog():
     buf = (C.c_uint8 * 27)()
     _ffi.lib().m1v_file_prolog(buf)
     return bytes(buf)
+
+
+# ---- the coarse entry point, as the reference spells it --------------------------------------------
+_LOAD_FN = C.CFUNCTYPE(C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int)
+_FREE_FN = C.CFUNCTYPE(None, C.c_void_p)
+_keepalive = {}
+
+
+def set_image_loader(load):
+    """Register a Python image loader with the library (include/encoder.h: encoder_set_image_loader).
+    `load(path: str) -> numpy uint8 array [H, W, C]` or None.  C callers normally get stb_image registered by
+    including encoder.h; Python callers can plug in any decoder (pixels then are that decoder's, not stb's)."""
+    import numpy as np
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+
+    def _load(path, pw, ph, pc, desired):
+        arr = load(path.decode())
+        if arr is None:
+            return None
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        h, w, c = arr.shape
+        buf = libc.malloc(arr.nbytes)
+        C.memmove(buf, arr.ctypes.data, arr.nbytes)
+        pw[0], ph[0], pc[0] = w, h, c
+        return buf
+
+    def _free(p):
+        libc.free(p)
+
+    cb = (_LOAD_FN(_load), _FREE_FN(_free))
+    _keepalive["loader"] = cb
+    _ffi.lib().encoder_set_image_loader(C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p))
+
+
+def mpeg_encode_procedure(images_folder, bitstream_folder, video_path, quality_factor, region=None):
+    """int mpeg_encode_procedure(images_folder, bitstream_folder, video_path, quality_factor) — the reference's
+    one public operator (include/encoder.h:20), same arguments, same return codes (0 ok, 1 cannot open video,
+    -1 folder/images/dimension problems).  region: None = library default (the reference's 96x144 corner unless
+    EC504_ENCODE_REGION=full), "strict" or "full"."""
+    L = _ffi.lib()
+    args = [str(images_folder).encode(), str(bitstream_folder).encode(), str(video_path).encode(), int(quality_factor)]
+    if region is None:
+        return L.mpeg_encode_procedure(*args)
+    return L.mpeg_encode_procedure_region(*args, 1 if region == "full" else 0)

@@ -108,3 +108,46 @@ def test_cli_end_to_end_vs_reference_binary(region, tmp_path):
         assert _run(CLI, str(d), "images/", "cli_bits", "cli_bits/v.mpeg", "12", region, env={"EC504_WRITE_BIT": "0"}) == 0
         assert (d / "cli_bits" / "v.mpeg").read_bytes() == theirs
         assert not (d / "cli_bits" / "image_1.bit").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("region,batch", [("full", 3), ("strict", 64)])
+def test_host_driver_with_a_custom_loader(region, batch, tmp_path, orc, monkeypatch):
+    """The C host driver (csrc/encoder_host.c) end to end on the GPU without stb: files named *.jpg hold raw pixels,
+    a Python loader registered through encoder_set_image_loader decodes them.  Checks readdir order, the ".jpg"
+    filter, batching (EC504_BATCH smaller than the folder), global frame indices across batches, the .mpeg bytes
+    and the image_<k>.bit side files against the oracle."""
+    import struct
+    from ec504_imageencoder_amd import mpeg_encode_procedure, set_image_loader
+    W, H, n = 208, 160, 8
+    frames = orc.synth_frames(n, W, H, seed=31)
+    img_dir, bit_dir = tmp_path / "images", tmp_path / "bits"
+    img_dir.mkdir()
+    for i in range(n):
+        (img_dir / f"frame_{i:02d}.jpg").write_bytes(struct.pack("<iii", W, H, 3) + frames[i].tobytes())
+    (img_dir / "notes.txt").write_text("not an image")
+    (img_dir / "broken.jpeg").write_bytes(b"xx")          # loader returns None -> skipped like a bad JPEG
+
+    def load(path):
+        raw = open(path, "rb").read()
+        if len(raw) < 12:
+            return None
+        w, h, c = struct.unpack_from("<iii", raw, 0)
+        return np.frombuffer(raw, np.uint8, w * h * c, 12).reshape(h, w, c)
+
+    set_image_loader(load)
+    monkeypatch.setenv("EC504_BATCH", str(batch))
+    video = tmp_path / "out.mpeg"
+    assert mpeg_encode_procedure(str(img_dir), str(bit_dir), str(video), 12, region=region) == 0
+    order = [e.name for e in os.scandir(img_dir) if ".jpg" in e.name]          # raw directory order, like readdir
+    idx = [int(nm[6:8]) for nm in order]
+    m = orc.MODE_FULL if region == "full" else orc.MODE_STRICT
+    want = orc.encode_sequence(frames[idx], n, W, H, 12, m)
+    assert video.read_bytes() == want
+    for k, i in enumerate(idx):
+        Y, Cb, Cr = orc.convert(frames[i])
+        assert (bit_dir / f"image_{k + 1}.bit").read_bytes() == struct.pack("<ii", W, H) + Y.tobytes() + Cb.tobytes() + Cr.tobytes()
+    monkeypatch.setenv("EC504_WRITE_BIT", "0")
+    bit2 = tmp_path / "bits2"
+    assert mpeg_encode_procedure(str(img_dir), str(bit2), str(tmp_path / "out2.mpeg"), 12, region=region) == 0
+    assert (tmp_path / "out2.mpeg").read_bytes() == want and not list(bit2.glob("*.bit"))
