@@ -19,23 +19,22 @@ sharedlib:
 	$(MAKE) -C $(PKG)/csrc
 	ln -sf $(PKG)/libencoder.so libencoder.so
 
-build/stb/stb_image.h:
-	mkdir -p build/stb
-	@if [ -f $(STB_DIR)/stb_image.h ]; then ln -sf $(STB_DIR)/stb_image.h $@; \
-	 else echo "stb_image.h not found in $(STB_DIR): the CLI is built without a JPEG loader"; fi
+# stb_image.h is looked up AFTER this repository's include/ (-idirafter): "encoder.h" always resolves to ours, and
+# when STB_DIR has no stb_image.h the callers are simply built without a JPEG loader.
+STB_INC := -idirafter $(STB_DIR)
 
-encoder: sharedlib build/stb/stb_image.h tools/encoder_cli.c include/encoder.h
-	$(CC) -O2 -w -Iinclude -Ibuild/stb tools/encoder_cli.c -o $@ -L$(PKG) -lencoder $(RPATH) -lm
+encoder: sharedlib tools/encoder_cli.c include/encoder.h
+	$(CC) -O2 -w -Iinclude $(STB_INC) tools/encoder_cli.c -o $@ -L$(PKG) -lencoder $(RPATH) -lm
 
-dropin: sharedlib build/stb/stb_image.h
+dropin: sharedlib
 	@test -f $(REF)/main.c || { echo "$(REF)/main.c absent"; exit 1; }
 	mkdir -p build
-	$(CC) -g -w -Iinclude -Ibuild/stb $(REF)/main.c -o build/dropin_encoder -L$(PKG) -lencoder $(RPATH) -lm
+	$(CC) -g -w -Iinclude $(STB_INC) $(REF)/main.c -o build/dropin_encoder -L$(PKG) -lencoder $(RPATH) -lm
 
-jni: sharedlib build/stb/stb_image.h
+jni: sharedlib
 	@test -n "$(JAVA_HOME)" -a -f "$(JAVA_HOME)/include/jni.h" || { echo "jni: needs a JDK (JAVA_HOME/include/jni.h)"; exit 1; }
 	mkdir -p build/jni/include && ln -sf ../../../include/encoder.h build/jni/include/encoder.h
-	$(CC) -g -w -fPIC -shared -Ibuild/jni -Iinclude -Ibuild/stb -I$(JAVA_HOME)/include -I$(JAVA_HOME)/include/linux \
+	$(CC) -g -w -fPIC -shared -Ibuild/jni -Iinclude $(STB_INC) -I$(JAVA_HOME)/include -I$(JAVA_HOME)/include/linux \
 	    $(REF)/encoder_jni.c -o libencoder_jni.so -L$(PKG) -lencoder $(RPATH) -lm
 
 oracle:
