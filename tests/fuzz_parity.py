@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fuzz soak on the GPU: random geometry / quality / channels / mode / dense run length / LDS image size / content
+"""(Not collected by pytest; run by hand on a GPU box: python tests/fuzz_parity.py 300)
+Fuzz soak on the GPU: random geometry / quality / channels / mode / dense run length / LDS image size / content
 class, HIP stream vs oracle stream, byte for byte.  usage: fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
@@ -7,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # this file lives in tests/: the oracle is test infrastructure
 import numpy as np
 import torch
 import oracle_ffi as orc
