@@ -1,5 +1,5 @@
 // ec504_imageencoder_amd/csrc/m1v_kernels.hip — MI355X (gfx950 / CDNA4) kernels and the C-ABI of
-// include/mpeg1_hip.h.  Written for gfx950 only: 64-wide waves, LDS-staged per-strip bit packing.
+// include/mpeg1_hip.h.  Written for gfx950 only: 64-wide waves, LDS-staged bit packing, 5 workgroups/CU.
 //
 // Data layout in HBM
 //   input    n_frames x (H x W x C) interleaved u8, as the reference's Image::data (jpeg_handler.h:6-11)
@@ -9,14 +9,22 @@
 //   output   contiguous frame records  PKT SEQ GOP PIC strips 00000000  (encoder.h:196-458)
 //
 // Kernels
-//   k_encode_strips   one workgroup per (frame, strip); one LANE per 8x8 block (Y0..Y3, Cb, Cr of each
-//                     macroblock down the strip).  Per lane: 8 rows x 24 B of RGB -> component (fp64,
-//                     unfused) -> two-pass integer FDCT in registers -> quantise -> zigzag -> DC/AC
-//                     code words.  Block bit lengths are prefix-summed across the workgroup, the
-//                     bits are OR-ed into an LDS image of the strip, and the strip is stored once.
-//   k_frame_layout    per frame: exclusive scan of strip byte counts
+//   k_encode_dense    the hot kernel (pictures whose strips hold >= 64 blocks).  A frame's blocks, in
+//                     stream order, are cut into runs of T consecutive blocks (default 256); one
+//                     workgroup per (frame, run), one LANE per 8x8 block (Y0..Y3, Cb, Cr of each
+//                     macroblock down the strip).  Per lane: 8 rows x 24 B of RGB -> component (three
+//                     fp32 FMAs; an unfused fp64 fix-up where the fp32 result is within 2 eps of an
+//                     integer, so results equal the reference's fp64 arithmetic bit for bit) ->
+//                     two-pass integer FDCT in registers -> quantise -> zigzag positions staged in LDS
+//                     as int8 (min AC divisor >= 8) or int16 -> DC/AC code words.  Bit lengths are
+//                     prefix-summed across the workgroup (DPP wave scan, one barrier), the bits are
+//                     OR-ed into an LDS image of the run (<= 2 byte-aligned strip segments) and stored
+//                     once.  Workgroups are dealt to XCDs so one frame's runs share an L2.
+//   k_encode_strips   one 64-lane workgroup per (frame, strip) for small pictures (< 64 blocks/strip)
+//   k_dense_frame_layout / k_frame_layout   per frame: strip bit/byte counts -> offsets
 //   k_frame_offsets   exclusive scan of frame sizes
-//   k_gather          strips -> final positions, frame headers, 16-bit length back-patch, trailer
+//   k_gather_dense / k_gather   strips -> final positions (funnel shift for non-aligned run pieces),
+//                     frame headers, 16-bit length back-patch, trailer
 //   k_coefficients    FDCT+quant+zigzag only (BASELINE config 2)
 //   k_convert, k_subsample, k_synth   plane conversion / 4:2:0 / synthetic input
 //
