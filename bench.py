@@ -59,6 +59,76 @@ def pmc_traffic(W, H, n):
     return None
 
 
+def cli_bench(args):
+    """the folder-level entry point end to end — a folder of JPEG files through ./encoder
+    (tools/encoder_cli.c -> mpeg_encode_procedure in libencoder.so: stb decode on the host pool, pinned staging,
+    HIP encode, .mpeg + image_<k>.bit written) timed as a whole process, beside the REAL reference binary
+    (oracle/_ref/ref_encoder_full, built from the reference's sources in the build container) on a bounded subset of
+    the same folder, whose files must be byte-identical to ours.  Not the headline metric: one JSON line of its own."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    W, H, n, qf = args.width, args.height, args.frames, args.quality
+    exe, ref = os.path.join(ROOT, "encoder"), os.path.join(ROOT, "oracle", "_ref", "ref_encoder_full")
+    if not os.path.exists(exe):
+        raise SystemExit("./encoder is not built (make encoder needs the reference's stb_image.h)")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(prefix="ec504_cli_", dir=base)
+    try:
+        rng = np.random.default_rng(504)
+        os.makedirs(os.path.join(d, "images"))
+        n_ref = min(n, args.cli_reference_frames)
+        os.makedirs(os.path.join(d, "subset"))
+        for i in range(n):          # smooth picture + noise: compressible like camera frames, every frame different
+            coarse = rng.integers(0, 256, (H // 40 + 1, W // 40 + 1, 3), dtype=np.uint8).repeat(40, 0).repeat(40, 1)[:H, :W]
+            img = np.clip(coarse.astype(np.int16) + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8)
+            path = os.path.join(d, "images", f"frame_{i:04d}.jpg")
+            Image.fromarray(img).save(path, quality=90)
+            if i < n_ref:
+                shutil.copy(path, os.path.join(d, "subset", f"frame_{i:04d}.jpg"))
+        jpeg_bytes = sum(e.stat().st_size for e in os.scandir(os.path.join(d, "images")))
+
+        def run(binary, images, tag, env=None, extra=()):
+            out = os.path.join(d, tag)
+            shutil.rmtree(out, ignore_errors=True)
+            os.makedirs(out)
+            e = dict(os.environ, EC504_ENCODE_REGION="full")
+            e.update(env or {})
+            t0 = time.perf_counter()
+            rc = subprocess.run([binary, images + "/", out, os.path.join(out, "v.mpeg"), str(qf), *extra], cwd=d, env=e,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+            dt = time.perf_counter() - t0
+            assert rc == 0, (binary, rc)
+            return dt, out
+
+        run(exe, "subset", "warm", extra=("full",))                 # page in the library and the GPU runtime once
+        res = {}
+        for tag, env in (("default", {}), ("no_bit_files", {"EC504_WRITE_BIT": "0"}),
+                         ("one_host_thread", {"EC504_HOST_THREADS": "1"})):
+            best = min(run(exe, "images", "ours_" + tag, env, ("full",))[0] for _ in range(args.cli_repeats))
+            res[tag] = {"seconds": round(best, 3), "frames_per_s": round(n / best, 1)}
+        line = {"metric": f"{W}x{H} JPEG folder -> .mpeg + .bit, frames/s (whole CLI process, end to end)",
+                "value": res["default"]["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+                "data": "synthetic", "dtype": "int32 (FDCT/VLC) + f64 (colour)", "vs_baseline": None,
+                "config": {"workload": f"{n} JPEG files {W}x{H} (quality 90, {jpeg_bytes / n / 1e3:.0f} KB each) in {os.path.dirname(d)}, "
+                                       f"FULL region, quality_factor {qf}, ./encoder = tools/encoder_cli.c + libencoder.so",
+                           "host_threads": os.cpu_count(), "runs": res}}
+        if os.path.exists(ref) and not args.no_cpu_baseline:
+            t_ref, ref_out = run(ref, "subset", "ref")
+            _, our_out = run(exe, "subset", "ours_subset", extra=("full",))
+            same = all(open(os.path.join(ref_out, f), "rb").read() == open(os.path.join(our_out, f), "rb").read()
+                       for f in ["v.mpeg"] + [f"image_{k}.bit" for k in range(1, n_ref + 1)])
+            line["cpu_baseline"] = {"value": round(n_ref / t_ref, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                    "sample": f"the reference's own ./encoder (FULL bounds) on the first {n_ref} files of the same folder, {t_ref:.1f} s",
+                                    "output_matches_reference": same}
+            assert same, "CLI output differs from the reference binary's"
+        print(json.dumps(line), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +146,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 code path on a box with ONE GPU: every rank encodes on cuda:0, "
                          "the bitstream gather goes through host memory (numbers are not meaningful)")
+    ap.add_argument("--cli", action="store_true",
+                    help="instead of the headline run: time the folder-of-JPEGs CLI path end to end (SURVEY 8f.1/8f.2)")
+    ap.add_argument("--cli-reference-frames", type=int, default=6)
+    ap.add_argument("--cli-repeats", type=int, default=2)
     args = ap.parse_args()
+    if args.cli:
+        if args.frames == 300:
+            args.frames = 128
+        return cli_bench(args)
 
     import numpy as np
     import torch

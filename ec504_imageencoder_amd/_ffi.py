@@ -19,13 +19,15 @@ _u8p = C.POINTER(C.c_uint8)
 MPEG1_HIP_SYMBOLS = [
     "m1v_device_count", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
     "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
+    "m1v_encode_planes_host",
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
 ]
 
 
-ENCODER_H_SYMBOLS = ["mpeg_encode_procedure", "mpeg_encode_procedure_region", "encoder_set_image_loader"]
+ENCODER_H_SYMBOLS = ["mpeg_encode_procedure", "mpeg_encode_procedure_region", "encoder_set_image_loader",
+                     "encoder_set_host_threads"]
 
 
 class EncoderLibraryMissing(RuntimeError):
@@ -71,6 +73,8 @@ def lib():
     L.m1v_free_host.restype = None
     L.m1v_encode_host.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.m1v_encode_host.restype = C.c_long
+    L.m1v_encode_planes_host.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp]
+    L.m1v_encode_planes_host.restype = C.c_long
     L.m1v_coefficients_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.m1v_coefficients_device.restype = C.c_int
     L.m1v_convert_device.argtypes = [vp, vp, C.c_int, vp, vp]

@@ -1441,6 +1441,8 @@ struct m1v_encoder {
         uint8_t *d_in, *d_out, *d_planes;
         unsigned long long *d_meta;
         size_t in_cap, out_cap, planes_cap, meta_cap;
+        hipStream_t copy_in, work; // upload stream; convert/encode/download stream
+        hipEvent_t uploaded[2];
     } hp;
     // profiling
     bool prof;
@@ -1647,6 +1649,10 @@ void m1v_destroy(m1v_encoder *e) {
     (void)hipFree(e->hp.d_out);
     (void)hipFree(e->hp.d_planes);
     (void)hipFree(e->hp.d_meta);
+    if (e->hp.copy_in) (void)hipStreamDestroy(e->hp.copy_in);
+    if (e->hp.work) (void)hipStreamDestroy(e->hp.work);
+    for (hipEvent_t ev : e->hp.uploaded)
+        if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_stamps);
     delete e;
 }
@@ -1905,27 +1911,48 @@ void m1v_free_host(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
-long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first_frame_index,
-                     uint8_t *out, size_t out_cap, uint64_t *frame_sizes) {
+long m1v_encode_planes_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first_frame_index,
+                            uint8_t *out, size_t out_cap, uint64_t *frame_sizes, uint8_t *planes) {
     if (!e || !rgb || !out) return fail(M1V_E_ARG, "null pointer%s");
     if (n_frames < 0 || n_frames > e->max_frames) return fail(M1V_E_ARG, "n_frames exceeds max_frames%s");
     if (n_frames == 0) return 0;
     HIP_TRY(hipSetDevice(e->device));
-    size_t in_bytes = (size_t)e->g.frame_bytes * n_frames;
+    const size_t frame_in = (size_t)e->g.frame_bytes, frame_planes = (size_t)e->g.W * e->g.H * 3;
+    size_t in_bytes = frame_in * n_frames;
     size_t bound = m1v_frame_bound(e) * (size_t)n_frames;
     size_t dcap = out_cap < bound ? out_cap : bound;
     m1v_encoder::HostPath &hp = e->hp;
     HIP_TRY(ensure_device(&hp.d_in, &hp.in_cap, in_bytes));
     HIP_TRY(ensure_device(&hp.d_out, &hp.out_cap, dcap));
     HIP_TRY(ensure_device(&hp.d_meta, &hp.meta_cap, (size_t)(n_frames + 2) * 8)); // [n] sizes, total, status
-    HIP_TRY(hipMemcpy(hp.d_in, rgb, in_bytes, hipMemcpyHostToDevice));
+    if (planes) HIP_TRY(ensure_device(&hp.d_planes, &hp.planes_cap, frame_planes * n_frames));
+    if (!hp.copy_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&hp.copy_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&hp.work, hipStreamNonBlocking));
+        for (hipEvent_t &ev : hp.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    // copy_in: H2D half A, H2D half B.   work: [planes A -> host] while B uploads, [planes B -> host], encode all.
+    const int half[3] = {0, planes && n_frames > 1 ? n_frames / 2 : n_frames, n_frames};
+    for (int h = 0; h < 2; h++) {
+        int f0 = half[h], nf = half[h + 1] - half[h];
+        if (nf == 0) continue;
+        HIP_TRY(hipMemcpyAsync(hp.d_in + frame_in * f0, rgb + frame_in * f0, frame_in * nf, hipMemcpyHostToDevice, hp.copy_in));
+        HIP_TRY(hipEventRecord(hp.uploaded[h], hp.copy_in));
+        HIP_TRY(hipStreamWaitEvent(hp.work, hp.uploaded[h], 0));
+        if (planes) {
+            int rc = m1v_convert_device(e, hp.d_in + frame_in * f0, nf, hp.d_planes + frame_planes * f0, hp.work);
+            if (rc != M1V_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(planes + frame_planes * f0, hp.d_planes + frame_planes * f0, frame_planes * nf,
+                                   hipMemcpyDeviceToHost, hp.work));
+        }
+    }
     int r = m1v_encode_device(e, hp.d_in, n_frames, first_frame_index, hp.d_out, dcap, (uint64_t *)hp.d_meta,
-                              (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), nullptr);
+                              (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), hp.work);
     if (r != M1V_OK) return r;
-    if (m1v_flush(e, nullptr) != M1V_OK) return M1V_E_HIP;
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (m1v_flush(e, hp.work) != M1V_OK) return M1V_E_HIP;
     std::vector<unsigned long long> meta((size_t)n_frames + 2);
-    HIP_TRY(hipMemcpy(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost, hp.work));
+    HIP_TRY(hipStreamSynchronize(hp.work));
     uint32_t status = (uint32_t)meta[(size_t)n_frames + 1];
     unsigned long long total = meta[n_frames];
     if (status & M1V_STATUS_UNENCODABLE)
@@ -1935,6 +1962,11 @@ long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first
     if (frame_sizes)
         for (int f = 0; f < n_frames; f++) frame_sizes[f] = meta[f];
     return (long)total;
+}
+
+long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first_frame_index,
+                     uint8_t *out, size_t out_cap, uint64_t *frame_sizes) {
+    return m1v_encode_planes_host(e, rgb, n_frames, first_frame_index, out, out_cap, frame_sizes, nullptr);
 }
 
 int m1v_coefficients_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int16_t *d_coeffs,

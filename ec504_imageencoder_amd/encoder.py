@@ -123,19 +123,22 @@ class Mpeg1Encoder:
             raise EncoderError(_ffi.E_NOSPACE, "encode")
         return out[:total].cpu().numpy().tobytes(), [int(s) for s in sizes[:rgb.shape[0]].cpu()]
 
-    def encode_host(self, rgb_np, first_frame_index=0):
-        """numpy uint8 [n,H,W,C] through the host-buffer entry point (PCIe inclusive)."""
+    def encode_host(self, rgb_np, first_frame_index=0, with_planes=False):
+        """numpy uint8 [n,H,W,C] through the host-buffer entry point (PCIe inclusive).  with_planes: also return the
+        uint8 [n,3,H*W] Y/Cb/Cr planes from the same upload (m1v_encode_planes_host: the image_<k>.bit content)."""
         import numpy as np
         rgb_np = np.ascontiguousarray(rgb_np, dtype=np.uint8)
         n = rgb_np.shape[0]
         cap = self.frame_bound * max(n, 1)
         out = np.empty(cap, np.uint8)
         sizes = np.zeros(max(n, 1), np.uint64)
-        rc = _ffi.lib().m1v_encode_host(self._h, rgb_np.ctypes.data, n, int(first_frame_index), out.ctypes.data,
-                                        cap, sizes.ctypes.data)
+        planes = np.empty((n, 3, self.height * self.width), np.uint8) if with_planes else None
+        rc = _ffi.lib().m1v_encode_planes_host(self._h, rgb_np.ctypes.data, n, int(first_frame_index), out.ctypes.data,
+                                               cap, sizes.ctypes.data, planes.ctypes.data if with_planes and n else None)
         if rc < 0:
-            raise EncoderError(rc, "m1v_encode_host")
-        return out[:rc].tobytes(), [int(s) for s in sizes[:n]]
+            raise EncoderError(rc, "m1v_encode_planes_host")
+        res = out[:rc].tobytes(), [int(s) for s in sizes[:n]]
+        return res + (planes,) if with_planes else res
 
     # ---- partial pipelines --------------------------------------------------------------------
     def coefficients(self, rgb):

@@ -61,6 +61,12 @@ typedef unsigned char *(*encoder_image_load_fn)(char const *path, int *w, int *h
 typedef void (*encoder_image_free_fn)(void *pixels);
 void encoder_set_image_loader(encoder_image_load_fn load, encoder_image_free_fn release);
 
+/* Host threads used for decoding (the loader is called from several threads at once: stbi_load is
+ * re-entrant), for staging pixels into pinned memory and for writing the image_<k>.bit files behind
+ * the GPU.  0 = one per online CPU (default), 1 = everything on the calling thread like the reference.
+ * The environment variable EC504_HOST_THREADS overrides it. */
+void encoder_set_host_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

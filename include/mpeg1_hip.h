@@ -101,6 +101,13 @@ int m1v_flush(m1v_encoder *enc, void *stream);
 long m1v_encode_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,
                      uint8_t *out, size_t out_cap, uint64_t *frame_sizes);
 
+/* m1v_encode_host plus, when planes != NULL, the full-resolution Y/Cb/Cr planes of m1v_convert_host from the SAME
+ * upload (what one frame-loop iteration of the reference produces: its frame record, encoder.h:196-458, and the
+ * content of image_<k>.bit, encoder.h:461-465).  The upload runs in two halves so the download of the first
+ * half's planes (PCIe is full duplex) overlaps the upload of the second. */
+long m1v_encode_planes_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,
+                            uint8_t *out, size_t out_cap, uint64_t *frame_sizes, uint8_t *planes);
+
 /* Pinned host memory for the buffers handed to the *_host entry points (optional; any host pointer works, pinned
  * ones are copied at the PCIe rate). */
 void *m1v_alloc_host(size_t bytes);

@@ -116,8 +116,11 @@ def test_golden_files_through_hip(torch_cuda, orc, fn):
         # host-buffer entry point gives the same bytes
         hgot, hsizes = enc.encode_host(rgb, 0)
         assert hgot == got and hsizes == sizes
-        # .bit side file planes
+        # .bit side file planes: from the device entry point and from the one-upload host entry point
+        # (m1v_encode_planes_host, two half-batch uploads overlapped with the plane downloads)
         planes = enc.convert(d).cpu().numpy()
+        pgot, psizes, hplanes = enc.encode_host(rgb, 0, with_planes=True)
+        assert pgot == got and psizes == sizes and np.array_equal(hplanes, planes)
         for i in range(n):
             blob = struct.pack("<ii", W, H) + planes[i].tobytes()
             assert hashlib.sha256(blob).hexdigest() == str(z["bit_sha256"][i])
