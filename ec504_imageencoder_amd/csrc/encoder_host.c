@@ -180,26 +180,15 @@ static void pool_close(Pool *p) {
 
 /* ---- the three kinds of host task ------------------------------------------------------------- */
 typedef struct {
-    char **path;
-    Image *img; /* img[i].data == NULL: the loader refused path[i] */
-    Pool *pool;
-    int have_first; /* set (under pool->mu) once any file has decoded; first = its geometry */
-    Image first;
+    char **path; /* the chunk's first file */
+    Image *img;  /* img[i].data == NULL afterwards: the loader refused path[i] */
 } DecodeJob;
 
 static void decode_task(void *ctx, int i) { /* encoder.h:162 */
     DecodeJob *j = (DecodeJob *)ctx;
     Image *im = &j->img[i];
+    if (im->data) return; /* the head file: decoded before the pipeline started */
     im->data = g_load(j->path[i], &im->width, &im->height, &im->channels, 0);
-    if (im->data) {
-        pthread_mutex_lock(&j->pool->mu);
-        if (!j->have_first) {
-            j->first = *im;
-            j->have_first = 1;
-            pthread_cond_broadcast(&j->pool->idle);
-        }
-        pthread_mutex_unlock(&j->pool->mu);
-    }
 }
 
 static void warm_task(void *ctx, int i) { /* start the GPU runtime while the first files decode */
@@ -242,6 +231,12 @@ static void bit_task(void *ctx, int i) {
     fwrite(&h, sizeof h, 1, f);
     fwrite(j->planes + (size_t)j->W * j->H * 3 * (size_t)i, 1, (size_t)j->W * j->H * 3, f);
     fclose(f);
+}
+
+static void remove_bit_file(const char *folder, int k) {
+    char path[256];
+    snprintf(path, sizeof path, "%s/image_%d.bit", folder, k);
+    (void)remove(path);
 }
 
 static double now_s(void) {
@@ -318,7 +313,17 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     int scan_failed = entry != NULL;
     closedir(dir);
 
-    int rc = -1;
+    /* The frame loop (encoder.h:196-486) as a pipeline over CHUNKS of `batch` consecutive files:
+     *
+     *     pool:   decode chunks c+1 .. c+look | stage chunk c+1 into pinned slot | write chunk c-1's .bit files
+     *     caller: chunk c through the GPU (one upload, frame records + planes back), append to the video
+     *
+     * so decoded pixels in flight are bounded by a few chunks whatever the folder holds.  The reference
+     * loads and checks EVERYTHING before it encodes (encoder.h:140-183); a folder it would reject is
+     * recognised here when the offending file is reached, and whatever was written until then is taken back
+     * (video truncated to its 27-byte prolog, side files removed), which is the state the reference leaves. */
+    enum { RING = 16 }; /* decode groups in flight, at most RING-1 chunks ahead of the GPU */
+    int rc = -1, mismatch = 0;
     const int timing = env_int("EC504_TIMING", 0); /* phase times on stderr */
     double t_phase[5] = {now_s(), 0, 0, 0, 0};
     Pool pool;
@@ -327,134 +332,145 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     m1v_encoder *enc = NULL;
     uint8_t *batch_in[2] = {NULL, NULL}, *planes[2] = {NULL, NULL}, *batch_out = NULL;
     uint64_t *sizes = NULL;
-    Group staged[2], written[2], warm, decoded;
+    Group staged[2], written[2], decoded[RING], warm;
+    DecodeJob dj[RING];
+    StageJob sj[2];
+    BitJob bj[2];
     memset(staged, 0, sizeof staged);
     memset(written, 0, sizeof written);
+    memset(decoded, 0, sizeof decoded);
     memset(&warm, 0, sizeof warm);
-    memset(&decoded, 0, sizeof decoded);
-    DecodeJob dj;
-    memset(&dj, 0, sizeof dj);
+    int frames_done = 0; /* frames encoded so far = global index of the next frame = .bit files written */
 
     imgs.v = (Image *)calloc((size_t)(n_paths ? n_paths : 1), sizeof(Image));
     if (scan_failed || !imgs.v) {
         printf("Error: Memory reallocation failed for images array.\n");
         goto done;
     }
-    imgs.cap = n_paths;
-    dj.path = paths, dj.img = imgs.v, dj.pool = &pool;
-    if (n_paths > 0 && pool.n_threads > 0) group_start(&pool, &warm, warm_task, NULL, 1);
-    group_start(&pool, &decoded, decode_task, &dj, n_paths);
-    group_wait_or(&pool, &decoded, &dj.have_first);
+    imgs.n = imgs.cap = n_paths;
+    if (n_paths > 0 && pool.n_threads > 0) group_start(&pool, &warm, warm_task, NULL, 1); /* GPU runtime start-up */
 
-    /* As soon as one file has decoded its geometry is (unless the folder is inconsistent, which the checks
-     * below reject exactly as before) the sequence's: set the GPU encoder and the pinned batch buffers up
-     * on this thread while the pool decodes the rest. */
-    const int write_bit = env_int("EC504_WRITE_BIT", 1);
-    int batch = 0, mrc = M1V_OK, alloc_ok = 1;
-    size_t frame_in = 0, bound = 0, out_cap = 0;
-    if (dj.have_first && dj.first.channels >= 3) {
-        frame_in = (size_t)dj.first.width * dj.first.height * dj.first.channels;
-        /* default batch: about 96 MB of pixels, 4..64 frames (pinned memory costs time to get and to give back) */
-        batch = env_int("EC504_BATCH", (int)((96u << 20) / (frame_in ? frame_in : 1)));
-        if (!getenv("EC504_BATCH")) batch = batch < 4 ? 4 : batch > 64 ? 64 : batch;
-        if (batch < 1) batch = 1;
-        if (batch > n_paths) batch = n_paths;
-        mrc = m1v_create(&enc, env_int("EC504_DEVICE", 0), dj.first.width, dj.first.height, dj.first.channels,
-                         quality_factor, region ? M1V_MODE_FULL : M1V_MODE_STRICT, batch);
-        if (mrc == M1V_OK) {
-            bound = m1v_frame_bound(enc);
-            /* pinned staging (copies to and from the GPU then run at the PCIe rate), two slots: while the GPU
-             * works on one, the pool fills the other and drains the previous planes into image_<k>.bit files.
-             * The output buffer starts at 1/16 of the worst case (white noise needs about 1/46 of it, pictures
-             * built to be expensive about 1/11) and grows on demand (see the batch loop). */
-            out_cap = bound * ((size_t)batch + 1) / 16;
-            batch_out = (uint8_t *)m1v_alloc_host(out_cap);
-            sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
-            alloc_ok = batch_out && sizes;
-            for (int s = 0; s < (batch < n_paths ? 2 : 1); s++) {
-                batch_in[s] = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
-                if (write_bit) planes[s] = (uint8_t *)m1v_alloc_host((size_t)dj.first.width * dj.first.height * 3 * (size_t)batch);
-                alloc_ok = alloc_ok && batch_in[s] && (!write_bit || planes[s]);
-            }
-        }
+    /* head: the first file that decodes fixes the geometry (and with it the batch size) */
+    int head = 0;
+    for (; head < n_paths; head++) {
+        Image *im = &imgs.v[head];
+        im->data = g_load(paths[head], &im->width, &im->height, &im->channels, 0);
+        if (im->data) break;
+        printf("Error loading image %s\n", paths[head]); /* reported and skipped, encoder.h:163-167 */
     }
-    t_phase[1] = now_s();
-    group_wait(&pool, &decoded);
-    t_phase[2] = now_s();
-
-    for (int i = 0; i < n_paths; i++) { /* unloadable files are reported and skipped, encoder.h:163-167 */
-        if (!imgs.v[i].data) {
-            printf("Error loading image %s\n", paths[i]);
-            continue;
-        }
-        imgs.v[imgs.n++] = imgs.v[i];
-    }
-    for (int i = imgs.n; i < n_paths; i++) imgs.v[i].data = NULL;
-
-    if (imgs.n == 0) { /* check_dimensions, image_processing.c:48-66 */
+    if (head == n_paths) { /* check_dimensions, image_processing.c:48-66 */
         printf("No images found in directory.\n");
         goto done;
     }
-    const int W = imgs.v[0].width, H = imgs.v[0].height, C = imgs.v[0].channels;
-    for (int i = 1; i < imgs.n; i++) {
-        if (imgs.v[i].width != W || imgs.v[i].height != H) {
-            printf("Error: Image dimensions do not match\n");
-            goto done;
-        }
-        if (imgs.v[i].channels != C) {
-            printf("Error: Image channel counts do not match\n");
-            goto done;
-        }
+    const int W = imgs.v[head].width, H = imgs.v[head].height, C = imgs.v[head].channels;
+    const size_t frame_in = (size_t)W * H * C, frame_planes = (size_t)W * H * 3;
+    /* default batch: about 96 MB of pixels, 4..64 frames (pinned memory costs time to get and to give back) */
+    int batch = env_int("EC504_BATCH", (int)((96u << 20) / (frame_in ? frame_in : 1)));
+    if (!getenv("EC504_BATCH")) batch = batch < 4 ? 4 : batch > 64 ? 64 : batch;
+    if (batch < 1) batch = 1;
+    if (batch > n_paths - head) batch = n_paths - head;
+    const int n_chunks = (n_paths - head + batch - 1) / batch;
+    /* enough chunks of decoding in flight to keep every thread busy (1.5 files per thread), 2..15 */
+    int look = (3 * (pool.n_threads + 1) / 2 + batch - 1) / batch;
+    look = look < 2 ? 2 : look > RING - 1 ? RING - 1 : look;
+#define CHUNK_FIRST(c) (head + (c) * batch)
+#define CHUNK_FILES(c) (n_paths - CHUNK_FIRST(c) < batch ? n_paths - CHUNK_FIRST(c) : batch)
+    int next_decode = 0;
+    for (; next_decode < n_chunks && next_decode < look; next_decode++) {
+        dj[next_decode] = (DecodeJob){paths + CHUNK_FIRST(next_decode), imgs.v + CHUNK_FIRST(next_decode)};
+        group_start(&pool, &decoded[next_decode], decode_task, &dj[next_decode], CHUNK_FILES(next_decode));
     }
+    t_phase[1] = now_s();
+
+    /* GPU encoder and pinned buffers, on this thread, while the pool decodes */
     if (C < 3) { /* image_processing.c:69-73 prints this and the reference then crashes */
         printf("Error: Image does not have correct color channels for RBG to YCbCr conversion.\n");
         goto done;
     }
-    if (mrc != M1V_OK || !enc) {
+    const int write_bit = env_int("EC504_WRITE_BIT", 1);
+    if (m1v_create(&enc, env_int("EC504_DEVICE", 0), W, H, C, quality_factor, region ? M1V_MODE_FULL : M1V_MODE_STRICT,
+                   batch) != M1V_OK) {
         printf("Error: cannot set up the GPU encoder: %s\n", m1v_last_error());
+        enc = NULL;
         goto done;
+    }
+    const size_t bound = m1v_frame_bound(enc);
+    /* pinned staging (copies to and from the GPU then run at the PCIe rate), two slots.  The output buffer
+     * starts at 1/16 of the worst case (white noise needs about 1/46 of it, pictures built to be expensive
+     * about 1/11) and grows on demand (see below). */
+    size_t out_cap = bound * ((size_t)batch + 1) / 16;
+    batch_out = (uint8_t *)m1v_alloc_host(out_cap);
+    sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
+    int alloc_ok = batch_out && sizes;
+    for (int s = 0; s < (n_chunks > 1 ? 2 : 1); s++) {
+        batch_in[s] = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
+        if (write_bit) planes[s] = (uint8_t *)m1v_alloc_host(frame_planes * (size_t)batch);
+        alloc_ok = alloc_ok && batch_in[s] && (!write_bit || planes[s]);
     }
     if (!alloc_ok) {
         printf("Error: Memory allocation failed.\n");
         goto done;
     }
-    if (batch > imgs.n) batch = imgs.n;
-    const int n_batches = (imgs.n + batch - 1) / batch;
-    const int n_slots = n_batches > 1 ? 2 : 1;
+    t_phase[2] = now_s();
 
-    StageJob sj[2];
-    BitJob bj[2];
-    sj[0] = (StageJob){imgs.v, batch_in[0], frame_in};
-    group_start(&pool, &staged[0], stage_task, &sj[0], batch);
-    for (int b = 0; b < n_batches; b++) { /* frame loop, encoder.h:196-486, one batch per pass */
-        const int s = b % n_slots, base = b * batch;
-        const int n = imgs.n - base < batch ? imgs.n - base : batch;
-        group_wait(&pool, &staged[s]);
-        if (b + 1 < n_batches) { /* the pool stages the next batch behind the GPU call below */
-            const int nb = base + batch, nn = imgs.n - nb < batch ? imgs.n - nb : batch;
-            sj[1 - s] = (StageJob){imgs.v + nb, batch_in[1 - s], frame_in};
-            group_start(&pool, &staged[1 - s], stage_task, &sj[1 - s], nn);
+    int n_cur = 0, n_next = 0; /* loaded frames of the chunk on the GPU / of the one being staged */
+    for (int c = -1; c < n_chunks; c++) {
+        const int s = c & 1;
+        if (c >= 0) group_wait(&pool, &staged[s]);
+        if (c >= 0 && next_decode < n_chunks) { /* keep `look` chunks of decoding ahead of the GPU */
+            const int r = next_decode % RING; /* ring entry of a chunk <= c-1, joined at least one pass ago */
+            dj[r] = (DecodeJob){paths + CHUNK_FIRST(next_decode), imgs.v + CHUNK_FIRST(next_decode)};
+            group_start(&pool, &decoded[r], decode_task, &dj[r], CHUNK_FILES(next_decode));
+            next_decode++;
         }
-        group_wait(&pool, &written[s]); /* planes[s] may still be on their way to disk (batch b-2) */
-        long total = m1v_encode_planes_host(enc, batch_in[s], n, base, batch_out, out_cap, sizes,
-                                            write_bit ? planes[s] : NULL);
-        if (total == M1V_E_NOSPACE && out_cap < bound * (size_t)batch) { /* rare: grow to the worst case, redo */
-            m1v_free_host(batch_out);
-            out_cap = bound * (size_t)batch;
-            batch_out = (uint8_t *)m1v_alloc_host(out_cap);
-            total = batch_out ? m1v_encode_planes_host(enc, batch_in[s], n, base, batch_out, out_cap, sizes,
-                                                       write_bit ? planes[s] : NULL)
-                              : M1V_E_HIP;
+        n_next = 0;
+        if (c + 1 < n_chunks) { /* join chunk c+1's decode, check it, let the pool stage it */
+            const int first = CHUNK_FIRST(c + 1), files = CHUNK_FILES(c + 1);
+            Image *v = imgs.v + first;
+            group_wait(&pool, &decoded[(c + 1) % RING]);
+            for (int i = 0; i < files; i++) {
+                if (!v[i].data) {
+                    printf("Error loading image %s\n", paths[first + i]);
+                    continue;
+                }
+                if (v[i].width != W || v[i].height != H) {
+                    if (!mismatch) printf("Error: Image dimensions do not match\n");
+                    mismatch = 1;
+                } else if (v[i].channels != C) {
+                    if (!mismatch) printf("Error: Image channel counts do not match\n");
+                    mismatch = 1;
+                }
+                v[n_next++] = v[i];
+            }
+            for (int i = n_next; i < files; i++) v[i].data = NULL;
+            if (mismatch) goto done;
+            sj[1 - s] = (StageJob){v, batch_in[(c + 1) & 1], frame_in};
+            group_start(&pool, &staged[(c + 1) & 1], stage_task, &sj[1 - s], n_next);
         }
-        if (total < 0) {
-            printf("Error: GPU encode failed: %s\n", m1v_last_error());
-            goto done;
+        if (c >= 0 && n_cur > 0) {
+            group_wait(&pool, &written[s]); /* planes[s] may still be on their way to disk (chunk c-2) */
+            long total = m1v_encode_planes_host(enc, batch_in[s], n_cur, frames_done, batch_out, out_cap, sizes,
+                                                write_bit ? planes[s] : NULL);
+            if (total == M1V_E_NOSPACE && out_cap < bound * (size_t)batch) { /* rare: grow to the worst case, redo */
+                m1v_free_host(batch_out);
+                out_cap = bound * (size_t)batch;
+                batch_out = (uint8_t *)m1v_alloc_host(out_cap);
+                total = batch_out ? m1v_encode_planes_host(enc, batch_in[s], n_cur, frames_done, batch_out, out_cap,
+                                                           sizes, write_bit ? planes[s] : NULL)
+                                  : M1V_E_HIP;
+            }
+            if (total < 0) {
+                printf("Error: GPU encode failed: %s\n", m1v_last_error());
+                goto done;
+            }
+            fwrite(batch_out, 1, (size_t)total, fp);
+            if (write_bit) { /* encoder.h:461-465, written behind the next chunk */
+                bj[s] = (BitJob){bitstream_folder, planes[s], frames_done + 1, W, H};
+                group_start(&pool, &written[s], bit_task, &bj[s], n_cur);
+            }
+            frames_done += n_cur;
         }
-        fwrite(batch_out, 1, (size_t)total, fp);
-        if (write_bit) { /* encoder.h:461-465, written behind the next batch */
-            bj[s] = (BitJob){bitstream_folder, planes[s], base + 1, W, H};
-            group_start(&pool, &written[s], bit_task, &bj[s], n);
-        }
+        n_cur = n_next;
     }
     printf("Image processing finished.\n");
     rc = 0;
@@ -462,16 +478,21 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
 
 done:
     group_wait(&pool, &warm); /* nothing may still reference what is freed below */
-    group_wait(&pool, &decoded);
+    for (int r = 0; r < RING; r++) group_wait(&pool, &decoded[r]);
     for (int s = 0; s < 2; s++) {
         group_wait(&pool, &staged[s]);
         group_wait(&pool, &written[s]);
     }
+    if (mismatch) { /* the reference rejects such a folder before it encodes anything */
+        fflush(fp);
+        if (ftruncate(fileno(fp), (off_t)sizeof prolog) != 0) perror("ftruncate");
+        for (int k = 1; k <= frames_done; k++) remove_bit_file(bitstream_folder, k);
+    }
     t_phase[4] = now_s();
     if (timing && rc == 0)
-        fprintf(stderr, "ec504 timing: %d files, %d threads, batch %d: first decode + gpu setup + pinned buffers %.3f s, "
-                        "rest of decode %.3f s, batches %.3f s, last .bit writes %.3f s\n", imgs.n, pool.n_threads + 1,
-                batch, t_phase[1] - t_phase[0], t_phase[2] - t_phase[1], t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
+        fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d: first decode %.3f s, gpu setup + pinned buffers "
+                        "%.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
+                t_phase[1] - t_phase[0], t_phase[2] - t_phase[1], t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
     pool_close(&pool);
     for (int s = 0; s < 2; s++) {
         m1v_free_host(batch_in[s]);
@@ -480,12 +501,13 @@ done:
     m1v_free_host(batch_out);
     free(sizes);
     m1v_destroy(enc);
-    imgs.n = n_paths; /* every slot that still holds pixels */
     release_images(&imgs);
     for (int i = 0; i < n_paths; i++) free(paths[i]);
     free(paths);
     fclose(fp);
     return rc;
+#undef CHUNK_FIRST
+#undef CHUNK_FILES
 }
 
 int mpeg_encode_procedure(const char *images_folder, const char *bitstream_folder,

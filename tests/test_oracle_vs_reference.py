@@ -281,3 +281,12 @@ def test_4k_strip_byte_and_dimension_wrap(ref, orc, tmp_path):
     rng = np.random.default_rng(4)
     d = _make_folder(tmp_path, "uhd", _synthetic(rng, 1, 3840, 2160, "smooth"), quality=75)
     _check_folder(ref, orc, d, 12)
+
+
+def test_more_than_255_strips_wraps_the_slice_byte(ref, orc, tmp_path):
+    # 4128 wide = 258 strips: the uint8 vertical position (mpeg1_blk.c slice start code) passes 0xFF, strip 255 is
+    # written as 00 00 01 00 and strips 256, 257 reuse 01, 02 — the reference does this, so the oracle must too
+    rng = np.random.default_rng(41)
+    d = _make_folder(tmp_path, "wide", _synthetic(rng, 2, 4128, 32, "noise"), quality=90)
+    _check_folder(ref, orc, d, 12, modes=("full",))
+

@@ -56,6 +56,16 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned *out, float2 *fo) {
     if (OP == 36) BODY("v_cmp_ne_u32 vcc, %0, %6\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_cmp_ne_u32 vcc, %2, %7\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n")
     if (OP == 37) BODY("v_mul_f32 %0, %0, %6 clamp\n v_mul_f32 %1, |%1|, %6 clamp\n v_min_u32 %2, %2, %7\n v_min_u32 %3, %3, %7\n")
     if (OP == 38) BODY("v_bfi_b32 %0, %6, %0, %7\n v_bfi_b32 %1, %6, %1, %7\n v_and_or_b32 %2, %2, %6, %7\n v_and_or_b32 %3, %3, %6, %7\n")
+    if (OP == 39) BODY("v_sub_f32_e64 %0, %6, |%0|\n v_sub_f32_e64 %1, %6, |%1|\n v_sub_f32_e64 %2, %7, |%2|\n v_sub_f32_e64 %3, %7, |%3|\n")
+    if (OP == 40) BODY("v_alignbit_b32 %0, %0, %6, 31\n v_alignbit_b32 %1, %1, %6, 31\n v_alignbit_b32 %2, %2, %7, 31\n v_alignbit_b32 %3, %3, %7, 31\n")
+    if (OP == 41) BODY("v_max3_f32 %0, %0, %6, %7\n v_max3_f32 %1, %1, %6, %7\n v_max3_f32 %2, %2, %6, %7\n v_max3_f32 %3, %3, %6, %7\n")
+    if (OP == 42) BODY("v_trunc_f32 %0, %0\n v_floor_f32 %1, %1\n v_rndne_f32 %2, %2\n v_trunc_f32 %3, %3\n")
+    if (OP == 43) BODY("v_dot2_i32_i16 %0, %0, %6, %7\n v_dot2_i32_i16 %1, %1, %6, %7\n v_dot2_u32_u16 %2, %2, %6, %7\n v_dot2_u32_u16 %3, %3, %6, %7\n")
+    if (OP == 44) BODY("v_cvt_pk_u8_f32 %0, %0, %6, %7\n v_cvt_pk_u8_f32 %1, %1, %6, %7\n v_cvt_pk_u8_f32 %2, %2, %6, %7\n v_cvt_pk_u8_f32 %3, %3, %6, %7\n")
+    if (OP == 45) BODY("v_max_f32 %0, %0, %6\n v_max_f32 %1, %1, %6\n v_min_f32 %2, %2, %7\n v_min_f32 %3, %3, %7\n")
+    if (OP == 46) BODY("v_sub_f32 %0, %6, %0\n v_add_f32 %1, %6, %1\n v_sub_f32 %2, %7, %2\n v_add_f32 %3, %7, %3\n")
+    if (OP == 47) BODY("v_fma_f32 %0, |%0|, %6, %7\n v_fma_f32 %1, -%1, %6, %7\n v_fma_f32 %2, %2, %6, -%7\n v_fma_f32 %3, %3, %6, %7 clamp\n")
+    if (OP == 48) BODY("v_mad_u32_u16 %0, %0, %6, %7\n v_mad_u32_u16 %1, %1, %6, %7\n v_mad_i32_i16 %2, %2, %6, %7\n v_mad_i32_i16 %3, %3, %6, %7\n")
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ (unsigned)b0 ^ (unsigned)b1;
 }
 
@@ -93,5 +103,9 @@ int main() {
     run<33>("v_add_u32_sdwa/v_mul_u32_u24_sdwa", d, f);
     run<34>("pair v_cmp(vcc)+v_cndmask_e32(vcc)", d, f); run<35>("pair v_cmp_e64(sgpr)+v_cndmask_e64", d, f);
     run<36>("pair v_cmp(vcc)+v_addc_co_u32", d, f); run<37>("v_mul_f32 clamp / v_min_u32", d, f); run<38>("v_bfi_b32/v_and_or_b32", d, f);
+    run<39>("v_sub_f32_e64 with |abs|", d, f); run<40>("v_alignbit_b32", d, f); run<41>("v_max3_f32", d, f);
+    run<42>("v_trunc/floor/rndne_f32", d, f); run<43>("v_dot2_i32_i16/u32_u16", d, f); run<44>("v_cvt_pk_u8_f32", d, f);
+    run<45>("v_max_f32/v_min_f32", d, f); run<46>("v_sub_f32/v_add_f32", d, f); run<47>("v_fma_f32 with modifiers", d, f);
+    run<48>("v_mad_u32_u16/v_mad_i32_i16", d, f);
     return 0;
 }
