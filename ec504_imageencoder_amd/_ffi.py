@@ -17,7 +17,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 # every symbol include/mpeg1_hip.h declares (tests check that the library exports all of them)
 MPEG1_HIP_SYMBOLS = [
-    "m1v_device_count", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
+    "m1v_device_count", "m1v_warm_up", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
     "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
     "m1v_encode_planes_host",
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
@@ -71,6 +71,8 @@ def lib():
     L.m1v_alloc_host.restype = vp
     L.m1v_free_host.argtypes = [vp]
     L.m1v_free_host.restype = None
+    L.m1v_warm_up.argtypes = [C.c_int]
+    L.m1v_warm_up.restype = C.c_int
     L.m1v_encode_host.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]
     L.m1v_encode_host.restype = C.c_long
     L.m1v_encode_planes_host.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp]

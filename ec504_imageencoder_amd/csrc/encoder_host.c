@@ -194,7 +194,7 @@ static void decode_task(void *ctx, int i) { /* encoder.h:162 */
 static void warm_task(void *ctx, int i) { /* start the GPU runtime while the first files decode */
     (void)ctx;
     (void)i;
-    (void)m1v_device_count();
+    (void)m1v_warm_up(env_int("EC504_DEVICE", 0));
 }
 
 typedef struct {
@@ -394,6 +394,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
         enc = NULL;
         goto done;
     }
+    const double t_created = now_s();
     const size_t bound = m1v_frame_bound(enc);
     /* pinned staging (copies to and from the GPU then run at the PCIe rate), two slots.  The output buffer
      * starts at 1/16 of the worst case (white noise needs about 1/46 of it, pictures built to be expensive
@@ -490,9 +491,10 @@ done:
     }
     t_phase[4] = now_s();
     if (timing && rc == 0)
-        fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d: first decode %.3f s, gpu setup + pinned buffers "
-                        "%.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
-                t_phase[1] - t_phase[0], t_phase[2] - t_phase[1], t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
+        fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d: first decode %.3f s, gpu encoder %.3f s, pinned "
+                        "buffers %.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
+                t_phase[1] - t_phase[0], t_created - t_phase[1], t_phase[2] - t_created, t_phase[3] - t_phase[2],
+                t_phase[4] - t_phase[3]);
     pool_close(&pool);
     for (int s = 0; s < 2; s++) {
         m1v_free_host(batch_in[s]);

@@ -1471,6 +1471,14 @@ int m1v_device_count(void) {
     return n;
 }
 
+int m1v_warm_up(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr)); // creates the context
+    hipFuncAttributes attr;    // loads this library's code object for the device
+    HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_frame_offsets)));
+    return M1V_OK;
+}
+
 size_t m1v_file_prolog(uint8_t out[27]) {
     static const uint8_t pack[9] = {0x00, 0x00, 0x01, 0xba, 0x21, 0x00, 0x01, 0x00, 0x01};
     memcpy(out, pack, 9);

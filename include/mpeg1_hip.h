@@ -97,6 +97,10 @@ int m1v_set_pipelined(m1v_encoder *enc, int enable);
 /* Makes `stream` wait for every gather still pending on the internal stream. */
 int m1v_flush(m1v_encoder *enc, void *stream);
 
+/* Starts the GPU runtime for `device` (context, code objects) so that a later m1v_create() does not pay for it.
+ * Optional; meant to be called from another thread while the caller is still busy with host work. */
+int m1v_warm_up(int device);
+
 /* Host-buffer convenience (PCIe inclusive, synchronous): returns total bytes or negative M1V_E_*. */
 long m1v_encode_host(m1v_encoder *enc, const uint8_t *rgb, int n_frames, int first_frame_index,
                      uint8_t *out, size_t out_cap, uint64_t *frame_sizes);

@@ -21,7 +21,7 @@ struct m1v_encoder {
 static const char *g_err = "";
 
 const char *m1v_last_error(void) { return g_err; }
-int m1v_device_count(void) { return 1; }
+int m1v_warm_up(int device) { (void)device; return M1V_OK; }
 size_t m1v_file_prolog(uint8_t out[27]) { return orc_file_prolog(out); }
 
 int m1v_create(m1v_encoder **out, int device, int w, int h, int channels, int qf, int mode, int max_frames) {
