@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned *out, float2 *fo) {
     if (OP == 46) BODY("v_sub_f32 %0, %6, %0\n v_add_f32 %1, %6, %1\n v_sub_f32 %2, %7, %2\n v_add_f32 %3, %7, %3\n")
     if (OP == 47) BODY("v_fma_f32 %0, |%0|, %6, %7\n v_fma_f32 %1, -%1, %6, %7\n v_fma_f32 %2, %2, %6, -%7\n v_fma_f32 %3, %3, %6, %7 clamp\n")
     if (OP == 48) BODY("v_mad_u32_u16 %0, %0, %6, %7\n v_mad_u32_u16 %1, %1, %6, %7\n v_mad_i32_i16 %2, %2, %6, %7\n v_mad_i32_i16 %3, %3, %6, %7\n")
+    if (OP == 49) BODY("v_fma_mix_f32 %0, %0, %6, %7 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %1, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %2, %6, %7 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n")
+    if (OP == 50) BODY("v_and_b32 %0, 0xff00ff, %0\n v_and_b32 %1, 0xff00ff, %1\n v_lshrrev_b32 %2, 8, %2\n v_lshrrev_b32 %3, 8, %3\n")
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ (unsigned)b0 ^ (unsigned)b1;
 }
 
@@ -106,6 +108,6 @@ int main() {
     run<39>("v_sub_f32_e64 with |abs|", d, f); run<40>("v_alignbit_b32", d, f); run<41>("v_max3_f32", d, f);
     run<42>("v_trunc/floor/rndne_f32", d, f); run<43>("v_dot2_i32_i16/u32_u16", d, f); run<44>("v_cvt_pk_u8_f32", d, f);
     run<45>("v_max_f32/v_min_f32", d, f); run<46>("v_sub_f32/v_add_f32", d, f); run<47>("v_fma_f32 with modifiers", d, f);
-    run<48>("v_mad_u32_u16/v_mad_i32_i16", d, f);
+    run<48>("v_mad_u32_u16/v_mad_i32_i16", d, f); run<49>("v_fma_mix_f32 (f16 src0)", d, f); run<50>("v_and_b32 literal / v_lshrrev", d, f);
     return 0;
 }
