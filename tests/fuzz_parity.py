@@ -41,7 +41,11 @@ def content(kind, n, H, W, C):
 
 t_end = time.time() + budget
 cases = fails = skipped = 0
+t_report = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_report:          # a line every 30 s: long silent runs look hung to the job runner
+        print(f"... {cases} cases, {fails} failures so far", flush=True)
+        t_report = time.time() + 30
     mode = "full" if rng.random() < 0.8 else "strict"
     W = int(rng.choice([16, 24, 96, 100, 176, 200, 352, 366, 640, 720, 1024, 1920]))
     H = int(rng.choice([16, 40, 144, 150, 288, 300, 480, 576, 1088, 1504, 2304]))
