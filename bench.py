@@ -132,8 +132,10 @@ def cli_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults long enough to sit past the GPU's clock ramp: after an idle start the first ~35 steps (35 ms) run up to
+    # 30 % slower (tools/step_ramp.py: 1.11 ms -> 0.86 ms per step), so short runs under-report the steady state
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

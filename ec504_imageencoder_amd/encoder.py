@@ -50,11 +50,15 @@ class Mpeg1Encoder:
         self.blocks_per_frame = self.strips * self.mb_rows * 6
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value and _ffi is not None and C is not None:
+        if getattr(self, "_h", None) is not None and self._h.value:
             _ffi.lib().m1v_destroy(self._h)
             self._h = C.c_void_p(0)
 
-    __del__ = close
+    def __del__(self):
+        try:        # at interpreter shutdown module globals may already be gone; the process is ending anyway
+            self.close()
+        except Exception:
+            pass
 
     # ---- the hot path -------------------------------------------------------------------------
     def encode(self, rgb, first_frame_index=0, out=None, sizes=None, meta=None):
