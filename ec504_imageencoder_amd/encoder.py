@@ -175,11 +175,12 @@ class Mpeg1Encoder:
             raise EncoderError(rc, "m1v_subsample_device")
         return a, b
 
-    def synth(self, n_frames, seed=504, first_frame_index=0, device=None):
-        """Device-generated synthetic frames (identical to oracle orc_synth_frame by definition)."""
+    def synth(self, n_frames, seed=504, first_frame_index=0, device=None, out=None):
+        """Device-generated synthetic frames (identical to oracle orc_synth_frame by definition).  out: reuse this tensor."""
         import torch
         dev = device or torch.device("cuda", self.device)
-        rgb = torch.empty((n_frames, self.height, self.width, self.channels), dtype=torch.uint8, device=dev)
+        rgb = out if out is not None else torch.empty((n_frames, self.height, self.width, self.channels), dtype=torch.uint8, device=dev)
+        assert rgb.numel() == n_frames * self.frame_bytes_in and rgb.is_contiguous()
         rc = _ffi.lib().m1v_synth_device(_ptr(rgb), self.frame_bytes_in, n_frames, seed, first_frame_index, _stream())
         if rc != _ffi.OK:
             raise EncoderError(rc, "m1v_synth_device")
