@@ -556,6 +556,47 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
 // non-zero mask, one column at a time (nothing but rows[] stays live).  Returns the DC level.
+// ---- tuning aid (tools/mkvariant.sh NAME -DM1V_ABL_CLASS=k, tools/ab.py): pads every block row with 16 extra
+// instructions of one class on a scratch register (results identical) to read the MARGINAL cost of that class in this
+// kernel's instruction mix; class 9 = only the scheduling barrier the padding implies.  0 (default) = nothing.
+#ifndef M1V_ABL_CLASS
+#define M1V_ABL_CLASS 0
+#endif
+#define M1V_REP16(x) x x x x x x x x x x x x x x x x
+__device__ __forceinline__ void abl_pad(uint32_t &d) {
+#if M1V_ABL_CLASS == 1
+    asm volatile(M1V_REP16("v_cvt_f32_ubyte1 %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 2
+    asm volatile(M1V_REP16("v_fma_f32 %0, %0, %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 3
+    asm volatile(M1V_REP16("v_add_u32 %0, %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 4
+    asm volatile(M1V_REP16("v_mad_i32_i24 %0, %0, %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 5
+    asm volatile(M1V_REP16("v_fract_f32 %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 6
+    asm volatile(M1V_REP16("v_cmp_lt_u32 vcc, %0, %0\n") : "+v"(d) : : "vcc");
+#elif M1V_ABL_CLASS == 7
+    asm volatile(M1V_REP16("v_cvt_i32_f32 %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 8
+    asm volatile(M1V_REP16("v_and_b32 %0, %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 9
+    asm volatile("" : "+v"(d));
+#elif M1V_ABL_CLASS == 10
+    asm volatile(M1V_REP16("s_add_u32 s100, s100, 1\n") : "+v"(d) : : "s100", "scc");
+#elif M1V_ABL_CLASS == 11
+    asm volatile(M1V_REP16("s_or_b64 s[100:101], s[100:101], exec\n") : "+v"(d) : : "s100", "s101", "scc");
+#elif M1V_ABL_CLASS == 12
+    asm volatile(M1V_REP16("s_nop 0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 13
+    asm volatile(M1V_REP16("v_mov_b32 %0, %0\n") : "+v"(d));
+#elif M1V_ABL_CLASS == 14
+    asm volatile(M1V_REP16("v_perm_b32 %0, %0, %0, %0\n") : "+v"(d));
+#else
+    (void)d;
+#endif
+}
+
 template <bool FAST, bool STAGE8>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
                                               const Row24 raw[8], const float *rq_t, uint32_t *stage, int T,
@@ -570,6 +611,13 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
         else
             load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
         fdct_row(px, &rows[i * 8]);
+#if M1V_ABL_CLASS
+        {
+            uint32_t abl; // dead after the padding: no register stays live across rows
+            asm volatile("v_mov_b32 %0, 0x3f9d70a4" : "=v"(abl));
+            abl_pad(abl);
+        }
+#endif
     }
     int dc = 0;
     nz = 0;
