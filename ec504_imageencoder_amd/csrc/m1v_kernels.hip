@@ -1014,6 +1014,8 @@ struct LayoutArgs {
     unsigned long long *frame_off;
     unsigned long long *out_frame_sizes; // may be null
     unsigned long long *out_total;       // may be null
+    uint32_t *enc_status;                // status bits of the encode kernel; handed on and cleared by k_frame_offsets
+    uint32_t *out_status;                // the caller's status word (or a private sink): the gather ORs into it
     int n_frames, n_strips;
 };
 
@@ -1066,7 +1068,13 @@ __global__ __launch_bounds__(1024) void k_frame_offsets(LayoutArgs a) {
         if (threadIdx.x == 0) carry += wsum[16];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && a.out_total) *a.out_total = carry;
+    if (threadIdx.x == 0) {
+        if (a.out_total) *a.out_total = carry;
+        // status hand-over (saves a memset before and a copy after every batch): the encode kernel is complete, the
+        // gather has not started; the word is zero again for the next batch that uses this set of buffers
+        *a.out_status = *a.enc_status;
+        *a.enc_status = 0;
+    }
 }
 
 struct GatherArgs {
@@ -1581,7 +1589,8 @@ static int configure_path(m1v_encoder *e, int dense_T) {
             if (err == hipSuccess) err = hipMalloc(&bt.strip_desc, nslots * sizeof(StripDesc));
             if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
-            if (err == hipSuccess) err = hipMalloc(&bt.status, sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.status, 2 * sizeof(uint32_t)); // [0] encode status, [1] sink
+            if (err == hipSuccess) err = hipMemset(bt.status, 0, 2 * sizeof(uint32_t));
             if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
             if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.gather_done, hipEventDisableTiming);
             if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
@@ -1822,7 +1831,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         HIP_TRY(hipStreamWaitEvent(st, bt.gather_done, 0));
         bt.gather_pending = false;
     }
-    HIP_TRY(hipMemsetAsync(bt.status, 0, sizeof(uint32_t), st));
     if (n_frames == 0) {
         if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, 4, st));
@@ -1837,6 +1845,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.frame_off = bt.frame_off;
     l.out_frame_sizes = (unsigned long long *)d_frame_sizes;
     l.out_total = (unsigned long long *)d_total;
+    l.enc_status = bt.status;
+    l.out_status = d_status ? d_status : bt.status + 1;
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
 
@@ -1899,7 +1909,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.tab = e->d_tab;
         ga.out = d_out;
         ga.out_cap = out_cap;
-        ga.status = bt.status;
+        ga.status = d_status ? d_status : bt.status + 1;
         ga.first_index = first_frame_index;
         hipLaunchKernelGGL(k_gather_dense, dim3(g.n_strips, n_frames), dim3(kGatherThreads), 0, gs, ga);
         HIP_TRY(hipGetLastError());
@@ -1939,7 +1949,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.tab = e->d_tab;
         ga.out = d_out;
         ga.out_cap = out_cap;
-        ga.status = bt.status;
+        ga.status = d_status ? d_status : bt.status + 1;
         ga.strip_cap = g.strip_cap;
         ga.n_frames = n_frames;
         ga.n_strips = g.n_strips;
@@ -1947,8 +1957,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, gs, ga);
         HIP_TRY(hipGetLastError());
     }
-    if (d_status)
-        HIP_TRY(hipMemcpyAsync(d_status, bt.status, sizeof(uint32_t), hipMemcpyDeviceToDevice, gs));
     if (e->pipelined) {
         HIP_TRY(hipEventRecord(bt.gather_done, gs));
         bt.gather_pending = true;
