@@ -15,7 +15,10 @@
  *       image_processing.c:400, encode_blk_coeff source/vlc.c:315, bit_vector.c appends),
  *       the strip zero-padding (encoder.h:442), the 16-bit length back-patch (encoder.h:448-453)
  *       and the 4 trailing bytes (encoder.h:456-458).
+ *   m1v_encode_planes_host     one frame-loop iteration per frame, complete: the frame record AND the planes that
+ *                              write_to_bitstream (image_processing.c:753, called at encoder.h:461-465) stores
  *   m1v_set_pipelined / m1v_flush   no reference counterpart: overlap of one batch's gather with the next encode
+ *   m1v_warm_up, m1v_alloc_host/_free_host   no reference counterpart: runtime start-up off the critical path, pinned buffers
  *   m1v_coefficients_device    fast_DCT + quantization + zigzag_scanning only (BASELINE config 2)
  *   m1v_convert_device/_host   convert_rgb_to_ycbcr, image_processing.c:68-110 (feeds the .bit files,
  *                              write_to_bitstream image_processing.c:753)
