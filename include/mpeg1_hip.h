@@ -29,6 +29,9 @@
  *
  * The coarse, drop-in entry point mpeg_encode_procedure() is declared in include/encoder.h.
  *
+ * Threads: an m1v_encoder is used by one thread at a time (different encoders, also on the same GPU, may be
+ * used concurrently); m1v_last_error() is per thread.
+ *
  * All *_device entry points are asynchronous on `stream` (a hipStream_t passed as void*, NULL =
  * the default stream) and take DEVICE pointers.  Return value: M1V_OK or a negative M1V_E_*.
  */

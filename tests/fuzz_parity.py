@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """(Not collected by pytest; run by hand on a GPU box: python tests/fuzz_parity.py 300)
 Fuzz soak on the GPU: random geometry / quality / channels / mode / dense run length / LDS image size / content
-class, HIP stream vs oracle stream, byte for byte.  usage: fuzz_parity.py [seconds] [seed]"""
+class, HIP stream vs oracle stream, byte for byte.  usage: fuzz_parity.py [seconds] [seed] [big]
+"big" draws large pictures (up to 4128 x 2304, up to 6 frames): fewer cases, long strips, many strips, offsets > 2^24."""
 import os
 import sys
 import time
@@ -15,6 +16,7 @@ import oracle_ffi as orc
 from ec504_imageencoder_amd import EncoderError, Mpeg1Encoder
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 
 
@@ -47,15 +49,19 @@ while time.time() < t_end:
         print(f"... {cases} cases, {fails} failures so far", flush=True)
         t_report = time.time() + 30
     mode = "full" if rng.random() < 0.8 else "strict"
-    W = int(rng.choice([16, 24, 96, 100, 176, 200, 352, 366, 640, 720, 1024, 1920]))
-    H = int(rng.choice([16, 40, 144, 150, 288, 300, 480, 576, 1088, 1504, 2304]))
+    if BIG:
+        W = int(rng.choice([1280, 1920, 2048, 2560, 3840, 4096, 4112, 4128]))
+        H = int(rng.choice([144, 720, 1080, 1088, 1440, 2160, 2304]))
+    else:
+        W = int(rng.choice([16, 24, 96, 100, 176, 200, 352, 366, 640, 720, 1024, 1920]))
+        H = int(rng.choice([16, 40, 144, 150, 288, 300, 480, 576, 1088, 1504, 2304]))
     if mode == "strict" and (W < 96 or H < 144):
         continue
-    if W * H > 1920 * 1200:
+    if not BIG and W * H > 1920 * 1200:
         continue
     C = 3 if rng.random() < 0.85 else 4
     qf = int(rng.choice([1, 5, 12, 12, 12, 25, 40, 50, 60, 75, 76, 77, 85, 92, 100]))
-    n = int(rng.integers(1, 5))
+    n = int(rng.integers(1, 7 if BIG else 5))
     kind = str(rng.choice(["noise", "extremes", "smooth", "blocks", "stripes"]))
     rgb = content(kind, n, H, W, C)
     first = int(rng.integers(0, 600))
