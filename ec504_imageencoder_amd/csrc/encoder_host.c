@@ -325,7 +325,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     enum { RING = 16 }; /* decode groups in flight, at most RING-1 chunks ahead of the GPU */
     int rc = -1, mismatch = 0;
     const int timing = env_int("EC504_TIMING", 0); /* phase times on stderr */
-    double t_phase[5] = {now_s(), 0, 0, 0, 0};
+    double t_phase[5] = {now_s(), 0, 0, 0, 0}, t_created = 0;
     Pool pool;
     pool_open(&pool, host_threads());
     ImageList imgs = {NULL, 0, 0};
@@ -394,7 +394,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
         enc = NULL;
         goto done;
     }
-    const double t_created = now_s();
+    t_created = now_s();
     const size_t bound = m1v_frame_bound(enc);
     /* pinned staging (copies to and from the GPU then run at the PCIe rate), two slots.  The output buffer
      * starts at 1/16 of the worst case (white noise needs about 1/46 of it, pictures built to be expensive
