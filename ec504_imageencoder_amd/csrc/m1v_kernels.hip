@@ -885,21 +885,26 @@ void k_encode_dense(DenseArgs a) {
 #pragma unroll
         for (int j = 0; j < kLutRegs; j++) {
             int idx = tid + j * T;
-            lutv[j] = idx < kLutWords ? a.tab->ac[idx] : 0u;
+            lutv[j] = a.tab->ac[min(idx, kLutWords - 1)]; // branch-free: the loads must stay countable (vmcnt)
         }
     }
-    uint32_t small_tab = 0; // this lane's word of the DC table (lanes 0..) or of the staging-slot map (lanes 32..)
-    if (tid < kDcWords) small_tab = a.tab->dc[tid];
-    if (tid >= 32 && tid < 32 + kSlotWords) small_tab = STAGE8 ? a.tab->slot8[tid - 32] : a.tab->slot[tid - 32];
+    // this lane's word of the DC table (lanes 0..31) or of the staging-slot map (lanes 32..47), one branch-free load
+    const uint32_t *small_src = tid < kDcWords ? &a.tab->dc[tid]
+                                               : (STAGE8 ? &a.tab->slot8[min(tid - 32, kSlotWords - 1)]
+                                                         : &a.tab->slot[min(tid - 32, kSlotWords - 1)]);
+    uint32_t small_tab = *small_src;
     // keep the table loads in front of the pixel loads (the scheduler otherwise hoists the pixel loads); a scheduling
     // barrier, not a memory clobber: a clobber would turn the later scalar table loads into vector loads
     __builtin_amdgcn_sched_barrier(0);
+    // Every lane loads (lanes past the end of the frame — last run only — re-load the frame's last block): outside any
+    // branch the sixteen loads stay countable, so the waits for the table words below are vmcnt(16) and the rows are
+    // consumed as they arrive (vmcnt(14), (12), ...) instead of after the last one.
     BlockSrc src;
     Row24 raw[8];
-    if (valid) {
-        int strip = in_b ? s0 + 1 : s0;
-        int pos = in_b ? tid - nA : pos0 + tid;
-        src = block_source(g, strip, pos);
+    {
+        const int gbc = min(gb, nb - 1);
+        const int strip = gbc / bps;
+        src = block_source(g, strip, gbc - strip * bps);
         if (FAST) load_block_rows(fbase, src, raw);
     }
 

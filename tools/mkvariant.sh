@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 cd $ROOT/ec504_imageencoder_amd/csrc
 mkdir -p $ROOT/build
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -fno-slp-vectorize -std=c++17 -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -Rpass-analysis=kernel-resource-usage -c m1v_kernels.hip -o $ROOT/build/m1v_kernels_$NAME.o 2> /tmp/mkvariant_$NAME.log || { grep error /tmp/mkvariant_$NAME.log; exit 1; }
 make -s encoder_host.o compat_primitives.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libencoder_$NAME.so $ROOT/build/m1v_kernels_$NAME.o encoder_host.o compat_primitives.o -lm
