@@ -164,7 +164,7 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
     return c;
 }
 
-// fp32 coefficients of the same three formulas, for the fast path below.  k0 carries -kEps.
+// fp32 coefficients of the same three formulas, for the fast path below.  k0 carries +256 - kEps.
 constexpr float kEps = 1.5e-4f;
 struct CompCoefF {
     float k0, kr, kg, kb;
@@ -172,7 +172,7 @@ struct CompCoefF {
 };
 __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     CompCoefF c;
-    c.k0 = (comp == 0 ? 0.0f : 128.0f) - kEps;
+    c.k0 = (comp == 0 ? 0.0f : 128.0f) + 256.0f - kEps;
     c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
     c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
     c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
@@ -180,30 +180,36 @@ __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     return c;
 }
 
-// Same value as component_fp64 for every (r,g,b), at fp32 cost.
-// The exact rational value x of a formula is a multiple of 1e-6 in [0.5, 255.5].  Three fp32 FMAs
-// starting from k0 - eps give t with |t - (x - eps)| <= d, d = 6e-5 (three half-ulps of 2^-16, three
-// coefficient roundings of 150 * 2^-24, the rounding of k0 - eps); the reference's fp64 result differs
-// from x by < 1e-12.  Let n = trunc(t), h = fract(t).  If h <= 1 - 2 eps then
-// x is in [n + eps - d, n + 1 - eps + d], i.e. at least 9e-5 inside (n, n+1), so trunc(fp64 result) == n.
-// Otherwise (x within 3.6e-4 of an integer: < 0.1 % of pixels, among them exactly the ties where fp64
-// rounding decides the byte) the lane re-evaluates the reference's fp64 expression.
-// tests: all 2^24 triples x 3 components on the GPU.
-// One pixel through the fast path; `h` = fract of the fp32 value (the caller decides on it).
-__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, float &h) {
+// Same value as component_fp64 for every (r,g,b), at fp32 cost and without a float->int conversion.
+// The exact rational value x of a formula is a multiple of 1e-6 in [0, 255.5].  Three fp32 FMAs starting
+// from k0 + 256 - eps give t with |t - (x + 256 - eps)| <= d < 1e-4 (three half-ulps of 2^-15, three
+// coefficient roundings, the rounding of the constant); the reference's fp64 result differs from x by
+// < 1e-12.  For t in [256, 512) the float's exponent is fixed, so its bits ARE a fixed-point number:
+//     bits >> 15      = 0x8700 + trunc(t - 256)        (kPxBias + the component value: the "raw" pixel)
+//     bits & 0x7fff   = fract(t) * 2^15
+// If the fraction field is < kFracLimit (fract(t) <= 1 - 2 eps), x lies at least eps - d inside
+// (n, n+1), so trunc(fp64 result) == n.  Otherwise (x an exact integer: 0.1-0.2 % of pixels, exactly the
+// ties where fp64 rounding decides the byte; t just below 256 also lands here) the lane re-evaluates the
+// reference's fp64 expression.  Raw pixels keep their bias through the FDCT: every butterfly input of a
+// multiplier is a difference (bias cancels), only the DC sum carries 64 * kPxBias, removed in fdct_col.
+// Proof over all 2^24 triples x 3 components: tools/colour_fast_proof.c (host) and the GPU tests.
+constexpr int kPxBias = 0x8700;
+constexpr uint32_t kFracLimit = 32758u; // floor((1 - 2 eps) * 2^15)
+__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, bool &uncertain) {
     float t = fmaf((float)b, k.kb, k.k0);
     t = fmaf((float)g, k.kg, t);
     t = fmaf((float)r, k.kr, t);
-    h = __builtin_amdgcn_fractf(t);
-    return (int)t;
+    uint32_t bits = __float_as_uint(t);
+    uncertain = (bits & 0x7fffu) >= kFracLimit;
+    return (int)(bits >> 15);
 }
-constexpr float kFractLimit = 1.0f - 2.0f * kEps;
+// raw pixel (kPxBias + value) of one component
 __device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
-    float h;
-    int q = component_fast(r, g, b, k, h);
-    if (!(h <= kFractLimit)) {
+    bool uncertain;
+    int q = component_fast(r, g, b, k, uncertain);
+    if (uncertain) {
         CompCoef d = comp_coef(k.comp);
-        q = component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
+        q = kPxBias + component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
     }
     return q;
 }
@@ -212,7 +218,7 @@ struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
 
-// 8 pixels of one block row (24 bytes already in registers) -> 8 component values.
+// 8 pixels of one block row (24 bytes already in registers) -> 8 raw component values (kPxBias + value).
 // One "is any pixel of this row uncertain?" branch per row instead of one per pixel: the branch is taken by
 // ~35 % of the waves, and then only the flagged pixels redo the fp64 expression (measured +6 % over
 // per-pixel branches: fewer scalar branch round trips in every wave's instruction stream).
@@ -227,20 +233,19 @@ __device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k
     bool bad[8], any = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        float h;
-        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, h);
-        bad[j] = !(h <= kFractLimit);
+        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, bad[j]);
         any |= bad[j];
     }
     if (any) {
         CompCoef d = comp_coef(k.comp);
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (bad[j]) out[j] = component_fp64((int)chan(j, 0), (int)chan(j, 1), (int)chan(j, 2), d.k0, d.kr, d.kg, d.kb);
+            if (bad[j])
+                out[j] = kPxBias + component_fp64((int)chan(j, 0), (int)chan(j, 1), (int)chan(j, 2), d.k0, d.kr, d.kg, d.kb);
     }
 }
 
-// 8 pixels of one block row -> 8 component values.  FAST: C == 3 and the row starts 4-byte aligned.
+// 8 pixels of one block row -> 8 raw component values.  FAST: C == 3 and the row starts 4-byte aligned.
 template <bool FAST>
 __device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, int out[8]) {
     if (FAST) {
@@ -304,13 +309,16 @@ __device__ __forceinline__ void fdct_row(const int p[8], int out[8]) {
     out[5] = __mul24(t[7], r2) >> 17;
 }
 
-// Column pass of one column (image_processing.c:253-305): rows[0..7][i] -> dct_block[0..7][i]
+// Column pass of one column (image_processing.c:253-305): rows[0..7][i] -> dct_block[0..7][i].
+// `dc_bias`: what the column's plain sum carries on top of the reference's value — 64 * kPxBias for column 0
+// of a block of raw pixels (row pass output 0 is the sum of 8 raw pixels), 0 for every other column.
 __device__ __forceinline__ void fdct_col(const int r0, const int r1, const int r2_, const int r3,
-                                         const int r4, const int r5, const int r6, const int r7, int c[8]) {
+                                         const int r4, const int r5, const int r6, const int r7, int c[8],
+                                         const int dc_bias) {
     constexpr int r2 = 181;
     int t[8];
     butterfly8(r0, r1, r2_, r3, r4, r5, r6, r7, t);
-    c[0] = (t[0] + 16) >> 3;
+    c[0] = (t[0] + (16 - dc_bias)) >> 3;
     c[4] = (t[1] + 16) >> 3;
     c[2] = (t[2] + 16384) >> 13;
     c[6] = (t[3] + 16384) >> 13;
@@ -320,7 +328,7 @@ __device__ __forceinline__ void fdct_col(const int r0, const int r1, const int r
     c[5] = (__mul24(t[7] >> 8, r2) + 8192) >> 12;
 }
 
-// px[i*8+j] -> c[u*8+i] (dct_block[u][i])
+// raw px[i*8+j] (kPxBias + value) -> c[u*8+i] (dct_block[u][i])
 __device__ __forceinline__ void fdct_block(const int px[64], int c[64]) {
     int rows[64];
 #pragma unroll
@@ -329,7 +337,7 @@ __device__ __forceinline__ void fdct_block(const int px[64], int c[64]) {
     for (int i = 0; i < 8; i++) {
         int col[8];
         fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], col);
+                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], col, i == 0 ? 64 * kPxBias : 0);
 #pragma unroll
         for (int u = 0; u < 8; u++) c[u * 8 + i] = col[u];
     }
@@ -625,7 +633,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     for (int i = 0; i < 8; i++) {
         int c[8], q[8];
         fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c);
+                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 64 * kPxBias : 0);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             q[u] = quant(c[u], rq_t[i * 8 + u]);
@@ -1323,6 +1331,7 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *rgb, int C, unsi
         const uint8_t *q = rgb + i * C;
         uint32_t r = q[0], gg = q[1], b = q[2];
         uint8_t *o = planes + f * 3 * npx_frame;
+        // raw pixel = kPxBias + value and kPxBias's low byte is zero
         o[p] = (uint8_t)component(r, gg, b, comp_coef_f(0));
         o[npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(1));
         o[2 * npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(2));

@@ -48,3 +48,16 @@ def test_narrow_staging_threshold(orc):
         q = orc.scale_qmatrix(qf)
         narrow = int(q[1:].min()) >= 8
         assert narrow == (qf <= 76), qf
+
+
+def test_colour_fast_path_proof_over_all_rgb_triples(tmp_path):
+    """The kernel's fp32 colour fast path (value and uncertainty flag read from the float's bit pattern, +256 so the
+    exponent is fixed) restated on the host and checked for all 2^24 triples x 3 components against the reference's
+    fp64 expression: every pixel it does not flag must already be right (tools/colour_fast_proof.c, 0.5 s)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "proof")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", os.path.join(root, "tools", "colour_fast_proof.c"), "-o", exe, "-lm"], check=True)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "wrong: 0" in p.stdout, p.stdout
