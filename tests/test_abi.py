@@ -119,3 +119,34 @@ def test_encode_kernels_do_not_spill(built):
         assert v.get("private_segment_fixed_size", 0) == 0, (k, v)
         assert v.get("vgpr_spill_count", 0) == 0, (k, v)
         assert v.get("vgpr_count", 999) <= 96, (k, v)
+
+
+def test_hot_kernel_consumes_pixel_rows_as_they_arrive(built):
+    """The dense kernel issues its table loads and its sixteen pixel loads outside any branch, so the compiler can
+    count them: the code tables are waited for with the pixels still in flight (vmcnt(16)) and every row is converted
+    as soon as ITS loads are back (vmcnt(14), (12) ... (0)).  One branch around one load silently turns all of these
+    into vmcnt(0) — correct, and 9 % slower — so the disassembly is checked."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "ec504_imageencoder_amd", "csrc", "m1v_kernels.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("llvm tools or object absent")
+    import glob
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(obj, os.path.join(td, "k.o"))
+        subprocess.run([objdump, "--offloading", "k.o"], cwd=td, capture_output=True, text=True)
+        cos = glob.glob(os.path.join(td, "k.o.*gfx950*"))
+        if not cos:
+            pytest.skip("cannot extract the gfx950 code object")
+        asm = subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True).stdout
+    for variant in ("k_encode_denseILb1ELb1", "k_encode_denseILb1ELb0"):      # the two aligned-input (FAST) variants
+        m = re.search(r"<_ZN\S*%s\S*>:\n(.*?)\n\n" % variant, asm, re.S)
+        assert m, variant
+        waits = [int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", m.group(1))]
+        assert 16 in waits, (variant, waits[:12])
+        i = waits.index(16)
+        seq = [w for w in waits[i:] if w % 2 == 0 and w <= 14]
+        want = [14, 12, 10, 8, 6, 4, 2, 0]
+        it = iter(seq)
+        assert all(any(w == x for x in it) for w in want), (variant, waits[:40])
