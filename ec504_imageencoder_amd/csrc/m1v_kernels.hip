@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mpeg1_hip.h"
@@ -556,6 +557,34 @@ __host__ __device__ constexpr int stage_slot8(int p) {
 }
 
 // Issue the 8 row loads (8 x 24 B) of one block.
+// Input modes of the dense kernel: 0 = byte loads (4 channels, or a buffer that is not 4-byte aligned),
+// 1 = 3 channels and every block row starts on a 4-byte boundary (width % 8 == 0): 24-byte loads,
+// 2 = 3 channels, block rows start anywhere in a 4-byte aligned buffer: 28 bytes from the dword at or below the row
+//     start, funnel-shifted by the lane's misalignment (v_alignbyte_b32).
+struct __attribute__((aligned(4))) Row28 {
+    uint32_t d[7];
+};
+__device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row28 raw[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *p = fbase + (src.first + (long long)i * src.stride) * 3;
+        const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - m);
+#pragma unroll
+        for (int k = 0; k < 6; k++) raw[i].d[k] = q[k];
+        // the seventh dword holds row bytes only when the row is misaligned; an aligned row must not touch it (it can lie
+        // beyond the end of the buffer), a misaligned one shares it with a byte of the row, i.e. with a mapped page
+        raw[i].d[6] = q[m ? 6 : 5];
+    }
+}
+__device__ __forceinline__ Row24 row_bytes(const Row24 &v, const uint8_t *) { return v; }
+__device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
+    const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
+    Row24 r;
+#pragma unroll
+    for (int k = 0; k < 6; k++) r.d[k] = __builtin_amdgcn_alignbyte(v.d[k + 1], v.d[k], m);
+    return r;
+}
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -605,9 +634,9 @@ __device__ __forceinline__ void abl_pad(uint32_t &d) {
 #endif
 }
 
-template <bool FAST, bool STAGE8>
+template <int FAST, bool STAGE8, typename RowT>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
-                                              const Row24 raw[8], const float *rq_t, uint32_t *stage, int T,
+                                              const RowT raw[8], const float *rq_t, uint32_t *stage, int T,
                                               int tid, unsigned long long &nz) {
     int rows[64];
     CompCoefF k = comp_coef_f(src.comp);
@@ -615,7 +644,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     for (int i = 0; i < 8; i++) {
         int px[8];
         if (FAST)
-            convert_row24(raw[i], k, px);
+            convert_row24(row_bytes(raw[i], fbase + (src.first + (long long)i * src.stride) * 3), k, px);
         else
             load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
         fdct_row(px, &rows[i * 8]);
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
 
     unsigned long long nz = 0;
     int dc = 0;
-    if (valid) dc = block_to_stage<FAST, false>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
+    if (valid) dc = block_to_stage<FAST ? 1 : 0, false>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
     auto fetch = [&](int p) -> int { return fetch_level<false>(slot_lut, stage, T, tid, p); };
 
     uint32_t hdr = 0;
@@ -851,7 +880,7 @@ struct DenseArgs {
     unsigned long long *stamps;
 };
 
-template <bool FAST, bool STAGE8>
+template <int FAST, bool STAGE8>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(M1V_WAVES_PER_EU, M1V_WAVES_PER_EU)))
 void k_encode_dense(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -908,7 +937,8 @@ void k_encode_dense(DenseArgs a) {
     // branch the sixteen loads stay countable, so the waits for the table words below are vmcnt(16) and the rows are
     // consumed as they arrive (vmcnt(14), (12), ...) instead of after the last one.
     BlockSrc src;
-    Row24 raw[8];
+    using RowT = typename std::conditional<FAST == 2, Row28, Row24>::type;
+    RowT raw[8];
     {
         const int gbc = min(gb, nb - 1);
         const int strip = gbc / bps;
@@ -933,7 +963,7 @@ void k_encode_dense(DenseArgs a) {
 
     unsigned long long nz = 0;
     int dc = 0;
-    if (valid) dc = block_to_stage<FAST, STAGE8>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
+    if (valid) dc = block_to_stage<FAST, STAGE8, RowT>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
     // The tables and the zeroed image written in the prologue are first read below (dc_header, walk_codes, pass 2);
     // the pixel stage only touches the lane's own staging column, so the waves of the workgroup do not meet before it
     // (+1.6 % over a barrier right after the prologue: no wave waits for the slowest wave's pixel loads).
@@ -1501,6 +1531,7 @@ struct m1v_encoder {
     unsigned calls;
     hipStream_t side;
     bool fast_ok;      // geometry allows the 4-byte-aligned 24-byte row loads
+    bool funnel_ok;    // debug switch (m1v_debug_set_input_mode): allow mode 2 (28-byte loads + funnel shift)
     Tables *d_tab;
     // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
     // pipelined mode batch k+1 can encode while batch k is still being gathered.
@@ -1664,6 +1695,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     memset(e->batch, 0, sizeof e->batch);
     memset(&e->hp, 0, sizeof e->hp);
     e->fast_ok = channels == 3 && (width % 8) == 0;
+    e->funnel_ok = true;
     e->prof = false;
     e->ev_used = 0;
     e->d_stamps = nullptr;
@@ -1701,8 +1733,9 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
 #endif
     if (err == hipSuccess) err = configure_path(e, 0) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
-    const void *kernels[] = {(const void *)&k_encode_dense<true, true>,  (const void *)&k_encode_dense<true, false>,
-                             (const void *)&k_encode_dense<false, true>, (const void *)&k_encode_dense<false, false>,
+    const void *kernels[] = {(const void *)&k_encode_dense<1, true>, (const void *)&k_encode_dense<1, false>,
+                             (const void *)&k_encode_dense<2, true>, (const void *)&k_encode_dense<2, false>,
+                             (const void *)&k_encode_dense<0, true>, (const void *)&k_encode_dense<0, false>,
                              (const void *)&k_encode_strips<true>,       (const void *)&k_encode_strips<false>};
     for (const void *kf : kernels)
         if (err == hipSuccess) err = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1895,15 +1928,21 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
         dim3 grid((unsigned)((size_t)n_frames * e->runs_per_frame)), block((unsigned)e->dense_T);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
-        if (fast && e->narrow)
-            hipLaunchKernelGGL((k_encode_dense<true, true>), grid, block, lds, st, a);
-        else if (fast)
-            hipLaunchKernelGGL((k_encode_dense<true, false>), grid, block, lds, st, a);
+        // input mode of the pixel loads (see load_block_rows): 1 = aligned rows, 2 = any row offset in an aligned
+        // buffer (3 channels), 0 = byte loads
+        const int mode = fast ? 1 : (g.C == 3 && ((uintptr_t)d_rgb & 3) == 0 && e->funnel_ok ? 2 : 0);
+        if (mode == 1 && e->narrow)
+            hipLaunchKernelGGL((k_encode_dense<1, true>), grid, block, lds, st, a);
+        else if (mode == 1)
+            hipLaunchKernelGGL((k_encode_dense<1, false>), grid, block, lds, st, a);
+        else if (mode == 2 && e->narrow)
+            hipLaunchKernelGGL((k_encode_dense<2, true>), grid, block, lds, st, a);
+        else if (mode == 2)
+            hipLaunchKernelGGL((k_encode_dense<2, false>), grid, block, lds, st, a);
         else if (e->narrow)
-            hipLaunchKernelGGL((k_encode_dense<false, true>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((k_encode_dense<0, true>), grid, block, lds, st, a);
         else
-            hipLaunchKernelGGL((k_encode_dense<false, false>), grid, block, lds, st, a);
-        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+            hipLaunchKernelGGL((k_encode_dense<0, false>), grid, block, lds, st, a);
         HIP_TRY(hipGetLastError());
         if (e->pipelined) {
             HIP_TRY(hipEventRecord(bt.enc_done, st));
