@@ -53,8 +53,8 @@ while time.time() < t_end:
         W = int(rng.choice([1280, 1920, 2048, 2560, 3840, 4096, 4112, 4128]))
         H = int(rng.choice([144, 720, 1080, 1088, 1440, 2160, 2304]))
     else:
-        W = int(rng.choice([16, 24, 96, 100, 176, 200, 352, 366, 640, 720, 1024, 1920]))
-        H = int(rng.choice([16, 40, 144, 150, 288, 300, 480, 576, 1088, 1504, 2304]))
+        W = int(rng.choice([16, 24, 96, 100, 101, 176, 200, 333, 352, 366, 640, 720, 1024, 1366, 1920]))
+        H = int(rng.choice([16, 40, 49, 144, 150, 288, 300, 301, 480, 576, 768, 1088, 1504, 2304]))
     if mode == "strict" and (W < 96 or H < 144):
         continue
     if not BIG and W * H > 1920 * 1200:

@@ -147,12 +147,15 @@ def test_golden_300_frames_hour_wrap(torch_cuda, orc):
                                            (1920, 1080, "full", 12, 3), (1920, 1080, "full", 30, 2), (400, 600, "full", 5, 2),
                                            (360, 250, "full", 12, 2), (366, 250, "full", 12, 2), (100, 150, "strict", 12, 2),
                                            (3840, 2160, "full", 12, 1), (32, 3008, "full", 12, 2), (16, 16, "full", 12, 9),
-                                           (4128, 32, "full", 12, 2), (7680, 4320, "full", 12, 1)])
+                                           (4128, 32, "full", 12, 2), (7680, 4320, "full", 12, 1),
+                                           (105, 49, "full", 12, 5), (1366, 768, "full", 12, 2), (333, 301, "full", 40, 3)])
 def test_random_frames_byte_exact(torch_cuda, orc, W, H, mode, qf, n):
     """Seeded synthetic frames: HIP stream == oracle stream, sizes too.  Covers the unaligned-width
     slow load path (366), tall strips that need the chunk loop (3008 rows = 1128 blocks per strip),
     4K (strip byte 0xF0, dimension wrap), the smallest picture, more than 255 strips (the uint8 slice byte wraps; the
-    oracle is pinned on this by tests/test_oracle_vs_reference.py) and 8K (480 strips, 194,400 blocks per frame)."""
+    oracle is pinned on this by tests/test_oracle_vs_reference.py), 8K (480 strips, 194,400 blocks per frame) and the
+    funnel-shifted 28-byte row loads (odd widths; 105x49x3 bytes per frame is odd, so frames are misaligned against each
+    other and the last row of the last frame ends the buffer)."""
     enc = _enc(W, H, qf, mode, max_frames=n)
     rgb = enc.synth(n, seed=1234 + W)
     got, sizes = enc.encode_to_bytes(rgb, first_frame_index=250)  # crosses the hour wrap at 256
