@@ -1943,6 +1943,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             hipLaunchKernelGGL((k_encode_dense<0, true>), grid, block, lds, st, a);
         else
             hipLaunchKernelGGL((k_encode_dense<0, false>), grid, block, lds, st, a);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         HIP_TRY(hipGetLastError());
         if (e->pipelined) {
             HIP_TRY(hipEventRecord(bt.enc_done, st));

@@ -412,3 +412,28 @@ def test_full_size_batch_properties(torch_cuda, orc):
         alone, _ = enc.encode_to_bytes(rgb[f:f + 1], first_frame_index=f)
         assert alone == want
     enc.close()
+
+
+def test_profile_events_bracket_only_the_encode_kernel(torch_cuda):
+    """m1v_profile_read (the source of bench.py's roofline.achieved) must time the dominant kernel alone: one pair of
+    events per launch, and their sum clearly below the wall time of the same launches, which also holds the layout and
+    gather kernels (a lost closing event once made it report the whole step)."""
+    import time
+    torch = torch_cuda
+    n, W, H = 100, 1920, 1080
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    rgb = enc.synth(n, seed=5)
+    for _ in range(30):
+        enc.encode(rgb)
+    torch.cuda.synchronize()
+    enc.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        enc.encode(rgb)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    launches, kernel_ms = enc.profile_read()
+    enc.profile(False)
+    assert launches == 20
+    assert 0.5 * wall_ms < kernel_ms < 0.97 * wall_ms, (kernel_ms, wall_ms)
+    enc.close()
