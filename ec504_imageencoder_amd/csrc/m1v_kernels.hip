@@ -223,9 +223,10 @@ struct __attribute__((aligned(4))) Row24 {
 // One "is any pixel of this row uncertain?" branch per row instead of one per pixel: the branch is taken by
 // ~35 % of the waves, and then only the flagged pixels redo the fp64 expression (measured +6 % over
 // per-pixel branches: fewer scalar branch round trips in every wave's instruction stream).
-__device__ __forceinline__ void convert_row24(const Row24 &v, const CompCoefF &k, int out[8]) {
+template <int BPP, typename RowT>
+__device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, int out[8]) {
     auto chan = [&](int j, int ch) -> uint32_t {
-        int byte = 3 * j + ch;
+        int byte = BPP * j + ch;
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
     // per-pixel flags live in scalar registers (compare results); keeping the eight fract values in VGPRs
@@ -251,7 +252,7 @@ template <bool FAST>
 __device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, int out[8]) {
     if (FAST) {
         Row24 v = *reinterpret_cast<const Row24 *>(p);
-        convert_row24(v, k, out);
+        convert_row<3>(v, k, out);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -577,6 +578,16 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
         raw[i].d[6] = q[m ? 6 : 5];
     }
 }
+//     3 = 4 channels in a 4-byte aligned buffer: 32-byte rows (always aligned); rows 0..3 are requested up front, rows
+//     4..7 from inside the row loop (64 raw registers would not fit next to the row-pass values).
+struct __attribute__((aligned(4))) Row32 {
+    uint32_t d[8];
+};
+__device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row32 raw[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        raw[i] = *reinterpret_cast<const Row32 *>(fbase + (src.first + (long long)i * src.stride) * 4);
+}
 __device__ __forceinline__ Row24 row_bytes(const Row24 &v, const uint8_t *) { return v; }
 __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
     const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
@@ -640,13 +651,23 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
                                               int tid, unsigned long long &nz) {
     int rows[64];
     CompCoefF k = comp_coef_f(src.comp);
+    Row32 late[FAST == 3 ? 4 : 1];
+    (void)late;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         int px[8];
-        if (FAST)
-            convert_row24(row_bytes(raw[i], fbase + (src.first + (long long)i * src.stride) * 3), k, px);
-        else
+        if constexpr (FAST == 3) {
+            if (i == 1) { // rows 4..7: requested once row 0 has been consumed
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    late[r] = *reinterpret_cast<const Row32 *>(fbase + (src.first + (long long)(r + 4) * src.stride) * 4);
+            }
+            convert_row<4>(i < 4 ? raw[i] : late[i - 4], k, px);
+        } else if constexpr (FAST != 0) {
+            convert_row<3>(row_bytes(raw[i], fbase + (src.first + (long long)i * src.stride) * 3), k, px);
+        } else {
             load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
+        }
         fdct_row(px, &rows[i * 8]);
 #if M1V_ABL_CLASS
         {
@@ -937,7 +958,7 @@ void k_encode_dense(DenseArgs a) {
     // branch the sixteen loads stay countable, so the waits for the table words below are vmcnt(16) and the rows are
     // consumed as they arrive (vmcnt(14), (12), ...) instead of after the last one.
     BlockSrc src;
-    using RowT = typename std::conditional<FAST == 2, Row28, Row24>::type;
+    using RowT = typename std::conditional<FAST == 3, Row32, typename std::conditional<FAST == 2, Row28, Row24>::type>::type;
     RowT raw[8];
     {
         const int gbc = min(gb, nb - 1);
@@ -1735,6 +1756,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = configure_path(e, 0) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
     const void *kernels[] = {(const void *)&k_encode_dense<1, true>, (const void *)&k_encode_dense<1, false>,
                              (const void *)&k_encode_dense<2, true>, (const void *)&k_encode_dense<2, false>,
+                             (const void *)&k_encode_dense<3, true>, (const void *)&k_encode_dense<3, false>,
                              (const void *)&k_encode_dense<0, true>, (const void *)&k_encode_dense<0, false>,
                              (const void *)&k_encode_strips<true>,       (const void *)&k_encode_strips<false>};
     for (const void *kf : kernels)
@@ -1930,7 +1952,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         // input mode of the pixel loads (see load_block_rows): 1 = aligned rows, 2 = any row offset in an aligned
         // buffer (3 channels), 0 = byte loads
-        const int mode = fast ? 1 : (g.C == 3 && ((uintptr_t)d_rgb & 3) == 0 && e->funnel_ok ? 2 : 0);
+        const bool aligned4 = ((uintptr_t)d_rgb & 3) == 0 && e->funnel_ok;
+        const int mode = fast ? 1 : (aligned4 && g.C == 3 ? 2 : (aligned4 && g.C == 4 ? 3 : 0));
         if (mode == 1 && e->narrow)
             hipLaunchKernelGGL((k_encode_dense<1, true>), grid, block, lds, st, a);
         else if (mode == 1)
@@ -1939,6 +1962,10 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             hipLaunchKernelGGL((k_encode_dense<2, true>), grid, block, lds, st, a);
         else if (mode == 2)
             hipLaunchKernelGGL((k_encode_dense<2, false>), grid, block, lds, st, a);
+        else if (mode == 3 && e->narrow)
+            hipLaunchKernelGGL((k_encode_dense<3, true>), grid, block, lds, st, a);
+        else if (mode == 3)
+            hipLaunchKernelGGL((k_encode_dense<3, false>), grid, block, lds, st, a);
         else if (e->narrow)
             hipLaunchKernelGGL((k_encode_dense<0, true>), grid, block, lds, st, a);
         else

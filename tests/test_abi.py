@@ -114,7 +114,7 @@ def test_encode_kernels_do_not_spill(built):
     if name:
         kernels[name] = fields
     dense = {k: v for k, v in kernels.items() if "k_encode_dense" in k}
-    assert len(dense) == 6, sorted(kernels)          # input modes 0, 1, 2 x narrow/wide staging
+    assert len(dense) == 8, sorted(kernels)          # input modes 0, 1, 2, 3 x narrow/wide staging
     for k, v in dense.items():
         assert v.get("vgpr_count", 999) <= 96, (k, v)
         # mode 1 (aligned 24-byte rows: the benchmarked configuration) and mode 0 must not touch scratch at all; mode 2
