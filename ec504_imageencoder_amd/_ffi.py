@@ -23,6 +23,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
+    "m1v_debug_set_input_mode",
 ]
 
 

@@ -15,8 +15,11 @@
  *
  * Deliberate differences (all on paths the reference's own driver never takes): bitvector_fwrite and
  * bitvector_toarray keep the final partial byte's valid bits; concat_char returns heap memory instead of a dangling stack pointer;
- * convert_ycbcr_to_rgb reads the planes it is given; VLC_encode / encode_blk_coeff report an uncodable level
- * by skipping it instead of dereferencing NULL.
+ * convert_ycbcr_to_rgb reads the planes it is given (the reference reads the buffer it has just allocated);
+ * VLC_encode / encode_blk_coeff report an uncodable level by skipping it instead of dereferencing NULL.
+ * Everything else — including the decoder-side helpers DCT, IDCT, fast_IDCT, dequantization, upsampling,
+ * insert_8x8_block, encode_macblk_encoding_value, mpeg1_sequence_end — is compared with the reference's own shared
+ * library in tests/test_compat_primitives.py (where /root/reference is present).
  */
 #define _DEFAULT_SOURCE
 #include <math.h>
@@ -255,7 +258,7 @@ BITVECTOR *encode_macblk_address_value(int value) {
 
 BITVECTOR *encode_macblk_encoding_value(int value) {
     if (value < -16 || value > 16) return NULL;
-    int n = value < 0 ? -value : value;
+    int n = value < 0 ? -value : 0; /* vlc.c:110-112: only a negative value selects its row; 1..16 code like 0 */
     BITVECTOR *r = bitvector_new(mv_encoding_table[n].binstring, mv_encoding_table[n].bit_len);
     if (value < 0) { /* the last bit becomes the sign */
         bitvector_pos(r, -1);
@@ -508,26 +511,43 @@ void insert_8x8_block(unsigned char *channel, int image_width, int start_x, int 
     for (int i = 0; i < 8; i++) memcpy(channel + (size_t)(start_y + i) * image_width + start_x, block[i], 8);
 }
 
-/* textbook orthonormal transforms (decoder-side helpers, unused by the driver) */
+/* textbook orthonormal transforms (decoder-side helpers, unused by the driver).  Same arithmetic as
+ * image_processing.c:157-179 and :452-474, so that results are bit-identical: the accumulator is a FLOAT updated once
+ * per term (each term formed in double from a float pixel / coefficient and two double cosines), the normalisation
+ * factors are doubles rounded to float and multiplied in float. */
+#define SHIM_PI 3.14159265358979323846
 void DCT(const unsigned char block[64], float dct_block[64]) {
     for (int u = 0; u < 8; u++)
         for (int v = 0; v < 8; v++) {
-            double s = 0;
+            float sum = 0.0f;
+            const float c_u = (float)(u == 0 ? sqrt(1.0 / 8) : sqrt(2.0 / 8));
+            const float c_v = (float)(v == 0 ? sqrt(1.0 / 8) : sqrt(2.0 / 8));
             for (int x = 0; x < 8; x++)
-                for (int y = 0; y < 8; y++)
-                    s += block[y * 8 + x] * cos((2 * x + 1) * u * M_PI / 16.0) * cos((2 * y + 1) * v * M_PI / 16.0);
-            dct_block[v * 8 + u] = (float)((u ? 0.5 : sqrt(0.125)) * (v ? 0.5 : sqrt(0.125)) * s);
+                for (int y = 0; y < 8; y++) {
+                    const float pixel = (float)block[y * 8 + x];
+                    const double term = (double)pixel * cos((2 * x + 1) * u * SHIM_PI / (2.0 * 8)) *
+                                        cos((2 * y + 1) * v * SHIM_PI / (2.0 * 8));
+                    sum = (float)((double)sum + term);
+                }
+            const float cc = c_u * c_v;
+            dct_block[v * 8 + u] = cc * sum;
         }
 }
 void IDCT(const float dct_block[64], unsigned char block[64]) {
     for (int x = 0; x < 8; x++)
         for (int y = 0; y < 8; y++) {
-            double s = 0;
+            float sum = 0.0f;
             for (int u = 0; u < 8; u++)
-                for (int v = 0; v < 8; v++)
-                    s += (u ? 0.5 : sqrt(0.125)) * (v ? 0.5 : sqrt(0.125)) * dct_block[v * 8 + u] *
-                         cos((2 * x + 1) * u * M_PI / 16.0) * cos((2 * y + 1) * v * M_PI / 16.0);
-            int p = (int)round(s);
+                for (int v = 0; v < 8; v++) {
+                    const float c_u = (float)(u == 0 ? sqrt(1.0 / 8) : sqrt(2.0 / 8));
+                    const float c_v = (float)(v == 0 ? sqrt(1.0 / 8) : sqrt(2.0 / 8));
+                    const float cc = c_u * c_v;
+                    const float scaled = cc * dct_block[v * 8 + u];
+                    const double term = (double)scaled * cos((2 * x + 1) * u * SHIM_PI / (2.0 * 8)) *
+                                        cos((2 * y + 1) * v * SHIM_PI / (2.0 * 8));
+                    sum = (float)((double)sum + term);
+                }
+            int p = (int)round(sum);
             block[y * 8 + x] = (unsigned char)(p < 0 ? 0 : p > 255 ? 255 : p);
         }
 }

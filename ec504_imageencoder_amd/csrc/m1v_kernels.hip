@@ -42,6 +42,12 @@
 
 #include "../../include/mpeg1_hip.h"
 
+#define M1V_HD __host__ __device__ __forceinline__
+#ifdef __HIP_DEVICE_COMPILE__
+#define M1V_MUL24(a, b) __mul24((a), (b))
+#endif
+#include "fdct_f32.h"
+
 #pragma clang fp contract(off) // colour conversion must stay unfused (image_processing.c:104-106)
 
 namespace {
@@ -53,7 +59,6 @@ constexpr int kWave = 64;
 constexpr int kAcRows = 32, kAcCols = 40;         // AC lookup: [run-1][|level|-1]
 constexpr int kLutWords = kAcRows * kAcCols;      // 1280
 constexpr int kDcWords = 32;                      // 2 x 9 used
-constexpr int kSlotWords = 16;                    // stage_slot table, 64 bytes
 constexpr int kMaxBlockBits = 886;
 constexpr int kDefaultLdsWords = 4096;            // 16 KiB strip image in LDS (strip-per-workgroup kernel)
 
@@ -72,13 +77,16 @@ __host__ __device__ constexpr int scan_inv(int p) {
     return -1;
 }
 
-// LDS staging of one lane's 64 levels: word row (u/2)*8 + i holds dct_block[u][i] (u even: low half,
-// u odd: high half), so a column's results can be stored as soon as that column is done.
-// stage_slot(p) = word_row*2 + half for zigzag position p.
-__host__ __device__ constexpr int stage_slot(int p) {
-    int k = scan_inv(p), u = k >> 3, i = k & 7;
-    return ((u >> 1) * 8 + i) * 2 + (u & 1);
-}
+// LDS staging of one block's 64 quantised levels, "zigzag class" layout.  A block owns kStageStride consecutive
+// words (an odd stride: the lanes of a wave hit different banks).  Narrow form (one BYTE per level, exact whenever no
+// AC level can reach +-128, which the host decides from the quantiser alone): word (p & 7) + 8 (p >> 5) holds the
+// levels at zigzag positions p, p+8, p+16, p+24 in its four bytes.  Wide form (int16): word (p & 15) + 16 (p >> 5)
+// holds positions p and p+16.  The point of the layout: the "is this byte non-zero" flags of one word, computed for
+// all four bytes at once, land on zigzag positions that differ by 8, so ONE shift puts them in place in the 64-bit
+// non-zero mask (stage_nonzero_mask) — 1.25 instructions per coefficient instead of a compare, a select and an OR.
+constexpr int kStageStride8 = 17, kStageStride16 = 33;
+__host__ __device__ constexpr int stage_byte8(int p) { return ((p & 7) + 8 * (p >> 5)) * 4 + ((p >> 3) & 3); }
+__host__ __device__ constexpr int stage_byte16(int p) { return ((p & 15) + 16 * (p >> 5)) * 4 + 2 * ((p >> 4) & 1); }
 
 // Device-resident tables, built by m1v_create.
 struct Tables {
@@ -86,8 +94,6 @@ struct Tables {
     float rq_t[64];             // the same, transposed [i][u]: one 32-byte scalar load per column pass
     uint32_t ac[kLutWords];     // (bits << 16) | code, 0 = escape.  [r][idx] with the reference's indexing
     uint32_t dc[kDcWords];      // [0..8] luma size codes, [16..24] chroma size codes
-    uint32_t slot[16];          // stage_slot(p) for p = 0..63, one byte each
-    uint32_t slot8[16];         // stage_slot8(p), the narrow (one byte per level) staging
     uint8_t hdr[256][44];       // PKT SEQ GOP PIC for hour = 0..255, length field zero
 };
 
@@ -165,7 +171,7 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
     return c;
 }
 
-// fp32 coefficients of the same three formulas, for the fast path below.  k0 carries +256 - kEps.
+// fp32 coefficients of the same three formulas, for the fast path below.  k0 carries +256 + kEps.
 constexpr float kEps = 1.5e-4f;
 struct CompCoefF {
     float k0, kr, kg, kb;
@@ -173,7 +179,7 @@ struct CompCoefF {
 };
 __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     CompCoefF c;
-    c.k0 = (comp == 0 ? 0.0f : 128.0f) + 256.0f - kEps;
+    c.k0 = (comp == 0 ? 0.0f : 128.0f) + 256.0f + kEps;
     c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
     c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
     c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
@@ -181,75 +187,85 @@ __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     return c;
 }
 
-// Same value as component_fp64 for every (r,g,b), at fp32 cost and without a float->int conversion.
-// The exact rational value x of a formula is a multiple of 1e-6 in [0, 255.5].  Three fp32 FMAs starting
-// from k0 + 256 - eps give t with |t - (x + 256 - eps)| <= d < 1e-4 (three half-ulps of 2^-15, three
-// coefficient roundings, the rounding of the constant); the reference's fp64 result differs from x by
-// < 1e-12.  For t in [256, 512) the float's exponent is fixed, so its bits ARE a fixed-point number:
-//     bits >> 15      = 0x8700 + trunc(t - 256)        (kPxBias + the component value: the "raw" pixel)
-//     bits & 0x7fff   = fract(t) * 2^15
-// If the fraction field is < kFracLimit (fract(t) <= 1 - 2 eps), x lies at least eps - d inside
-// (n, n+1), so trunc(fp64 result) == n.  Otherwise (x an exact integer: 0.1-0.2 % of pixels, exactly the
-// ties where fp64 rounding decides the byte; t just below 256 also lands here) the lane re-evaluates the
-// reference's fp64 expression.  Raw pixels keep their bias through the FDCT: every butterfly input of a
-// multiplier is a difference (bias cancels), only the DC sum carries 64 * kPxBias, removed in fdct_col.
+// Same value as component_fp64 for every (r,g,b), at fp32 cost, and already the float the fp32 FDCT (fdct_f32.h) takes.
+// The exact rational value x of a formula is a multiple of 1e-6 in [0, 255.5].  Three fp32 FMAs starting from
+// k0 + 256 + eps give t = x + 256 + eps + e with |e| < 1e-4 < eps (three half-ulps of 2^-15, three coefficient
+// roundings, the rounding of the constant); the reference's fp64 result differs from x by < 1e-12.  t lies in
+// [256, 512) for every input, so the float's exponent is fixed and its low 15 mantissa bits are the fraction:
+//     raw pixel      p = t with those 15 bits cleared = 256 + trunc(t - 256)     (one v_and_b32; kPxBiasF + value)
+//     fraction       d = t - p                                                   (exact)
+// If d >= kFracLow (> 2 eps) then x >= trunc(t - 256) + d - eps - 1e-4 lies at least 0.5e-4 above that integer and,
+// as d < 1, at least eps - 1e-4 below the next one: trunc(fp64 result) == trunc(t - 256).  Otherwise (x an exact
+// integer — where fp64 rounding decides the byte — or less than 1.5e-4 above one: 0.16 % of the pixels) the lane
+// re-evaluates the reference's fp64 expression.  The row's smallest d is reduced with v_min3_f32 (two pixels per
+// instruction) and compared once per row.  Raw pixels keep their bias through the FDCT: every multiplier input of the
+// butterflies is a difference (bias cancels), only the DC sum carries 64 * kPxBiasF, removed in fdct_col_f.
 // Proof over all 2^24 triples x 3 components: tools/colour_fast_proof.c (host) and the GPU tests.
-constexpr int kPxBias = 0x8700;
-constexpr uint32_t kFracLimit = 32758u; // floor((1 - 2 eps) * 2^15)
-__device__ __forceinline__ int component_fast(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k, bool &uncertain) {
+constexpr float kFracLow = 10.0f / 32768.0f;
+__device__ __forceinline__ float component_t(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
     float t = fmaf((float)b, k.kb, k.k0);
     t = fmaf((float)g, k.kg, t);
-    t = fmaf((float)r, k.kr, t);
-    uint32_t bits = __float_as_uint(t);
-    uncertain = (bits & 0x7fffu) >= kFracLimit;
-    return (int)(bits >> 15);
+    return fmaf((float)r, k.kr, t);
 }
-// raw pixel (kPxBias + value) of one component
-__device__ __forceinline__ int component(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
-    bool uncertain;
-    int q = component_fast(r, g, b, k, uncertain);
-    if (uncertain) {
+__device__ __forceinline__ float clear_fraction(float t) { return __uint_as_float(__float_as_uint(t) & 0xffff8000u); }
+// raw pixel (kPxBiasF + value) of one component, per-pixel branch (plane conversion and the byte-load input mode)
+__device__ __forceinline__ float component_raw(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
+    const float t = component_t(r, g, b, k);
+    float p = clear_fraction(t);
+    if (t - p < kFracLow) {
         CompCoef d = comp_coef(k.comp);
-        q = kPxBias + component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
+        p = m1vf::kPxBiasF + (float)component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
     }
-    return q;
+    return p;
 }
 
 struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
 
-// 8 pixels of one block row (24 bytes already in registers) -> 8 raw component values (kPxBias + value).
-// One "is any pixel of this row uncertain?" branch per row instead of one per pixel: the branch is taken by
-// ~35 % of the waves, and then only the flagged pixels redo the fp64 expression (measured +6 % over
-// per-pixel branches: fewer scalar branch round trips in every wave's instruction stream).
+// 8 pixels of one block row (24 or 32 bytes already in registers) -> 8 raw pixels.  One "is any pixel of this row
+// uncertain?" branch per row instead of one per pixel: the branch is taken by about half of the waves, and then only
+// the flagged pixels redo the fp64 expression.
 template <int BPP, typename RowT>
-__device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, int out[8]) {
+__device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, float out[8]) {
     auto chan = [&](int j, int ch) -> uint32_t {
         int byte = BPP * j + ch;
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
-    // per-pixel flags live in scalar registers (compare results); keeping the eight fract values in VGPRs
-    // instead (one v_max per pixel, one compare per row) measured +1 % but tips the kernel over its 96-VGPR
-    // budget in some builds (168 B/lane of scratch = 1.7x slower), so the robust form is used
-    bool bad[8], any = false;
+    float lowest = 1.0f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        out[j] = component_fast(chan(j, 0), chan(j, 1), chan(j, 2), k, bad[j]);
-        any |= bad[j];
+    for (int j = 0; j < 8; j += 2) {
+        const float t0 = component_t(chan(j, 0), chan(j, 1), chan(j, 2), k);
+        const float t1 = component_t(chan(j + 1, 0), chan(j + 1, 1), chan(j + 1, 2), k);
+        out[j] = clear_fraction(t0);
+        out[j + 1] = clear_fraction(t1);
+        lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
     }
-    if (any) {
+    if (lowest < kFracLow) { // rare: redo the row's flagged pixels in the reference's arithmetic
+        // The fractions are recomputed here from the row's bytes (same instructions, same values) instead of being kept
+        // alive across the branch: eight more live registers in the common path would push the kernel over its
+        // 96-VGPR budget.  The empty asm hides the bytes' origin from common-subexpression elimination.
+        RowT w = v;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(RowT) / 4); i++) asm("" : "+v"(w.d[i]));
+        auto chan2 = [&](int j, int ch) -> uint32_t {
+            int byte = BPP * j + ch;
+            return (w.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+        };
         CompCoef d = comp_coef(k.comp);
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (bad[j])
-                out[j] = kPxBias + component_fp64((int)chan(j, 0), (int)chan(j, 1), (int)chan(j, 2), d.k0, d.kr, d.kg, d.kb);
+        for (int j = 0; j < 8; j++) {
+            const uint32_t r = chan2(j, 0), gg = chan2(j, 1), b = chan2(j, 2);
+            const float t = component_t(r, gg, b, k);
+            if (t - clear_fraction(t) < kFracLow)
+                out[j] = m1vf::kPxBiasF + (float)component_fp64((int)r, (int)gg, (int)b, d.k0, d.kr, d.kg, d.kb);
+        }
     }
 }
 
-// 8 pixels of one block row -> 8 raw component values.  FAST: C == 3 and the row starts 4-byte aligned.
+// 8 pixels of one block row -> 8 raw pixels.  FAST: C == 3 and the row starts 4-byte aligned.
 template <bool FAST>
-__device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, int out[8]) {
+__device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, float out[8]) {
     if (FAST) {
         Row24 v = *reinterpret_cast<const Row24 *>(p);
         convert_row<3>(v, k, out);
@@ -257,98 +273,20 @@ __device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoef
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint8_t *q = p + j * C;
-            out[j] = component(q[0], q[1], q[2], k);
+            out[j] = component_raw(q[0], q[1], q[2], k);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// block stage: the reference's integer FDCT (image_processing.c:192-307), in registers
+// block stage: the reference's integer FDCT (image_processing.c:192-307) in exact fp32 arithmetic, in registers:
+// fdct_f32.h (m1vf::fdct_row_f, m1vf::fdct_col_f).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void butterfly8(const int v0, const int v1, const int v2, const int v3,
-                                           const int v4, const int v5, const int v6, const int v7,
-                                           int t[8]) {
-    constexpr int c1 = 1004, s1 = 200, c3 = 851, s3 = 569, r2c6 = 554, r2s6 = 1337;
-    int a0 = v0 + v7, d0 = v0 - v7;
-    int a1 = v1 + v6, d1 = v1 - v6;
-    int a2 = v2 + v5, d2 = v2 - v5;
-    int a3 = v3 + v4, d3 = v3 - v4;
-    int e0 = a0 + a3, e3 = a0 - a3;
-    int e1 = a1 + a2, e2 = a1 - a2;
-    // Every multiplicand fits 24 bits for u8 pixels (row pass |operand| <= 2^21, column pass <= 2^15;
-    // worst-case interval bounds in DESIGN.md), so the full-rate 24-bit multiplier is exact here.
-    int m12 = __mul24(c1, d1 + d2);
-    int f2 = __mul24(-s1 - c1, d2) + m12;
-    int f1 = __mul24(s1 - c1, d1) + m12;
-    int m03 = __mul24(c3, d0 + d3);
-    int f3 = __mul24(-s3 - c3, d3) + m03;
-    int f0 = __mul24(s3 - c3, d0) + m03;
-    t[0] = e0 + e1;                       // x6
-    t[1] = e0 - e1;                       // x4
-    int m78 = __mul24(r2c6, e2 + e3);
-    t[3] = __mul24(-r2s6 - r2c6, e2) + m78; // x7
-    t[2] = __mul24(r2s6 - r2c6, e3) + m78;  // x8
-    int g5 = f0 + f2, g0 = f0 - f2;
-    int g2 = f3 + f1, g3 = f3 - f1;
-    t[4] = g2 - g5;
-    t[5] = g2 + g5;
-    t[6] = g3;
-    t[7] = g0;
-}
-
-// Row pass of one row (image_processing.c:198-250): 8 pixels -> rows[i][0..7]
-__device__ __forceinline__ void fdct_row(const int p[8], int out[8]) {
-    constexpr int r2 = 181;
-    int t[8];
-    butterfly8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], t);
-    out[0] = t[0];
-    out[4] = t[1];
-    out[2] = t[2] >> 10;
-    out[6] = t[3] >> 10;
-    out[7] = t[4] >> 10;
-    out[1] = t[5] >> 10;
-    out[3] = __mul24(t[6], r2) >> 17;
-    out[5] = __mul24(t[7], r2) >> 17;
-}
-
-// Column pass of one column (image_processing.c:253-305): rows[0..7][i] -> dct_block[0..7][i].
-// `dc_bias`: what the column's plain sum carries on top of the reference's value — 64 * kPxBias for column 0
-// of a block of raw pixels (row pass output 0 is the sum of 8 raw pixels), 0 for every other column.
-__device__ __forceinline__ void fdct_col(const int r0, const int r1, const int r2_, const int r3,
-                                         const int r4, const int r5, const int r6, const int r7, int c[8],
-                                         const int dc_bias) {
-    constexpr int r2 = 181;
-    int t[8];
-    butterfly8(r0, r1, r2_, r3, r4, r5, r6, r7, t);
-    c[0] = (t[0] + (16 - dc_bias)) >> 3;
-    c[4] = (t[1] + 16) >> 3;
-    c[2] = (t[2] + 16384) >> 13;
-    c[6] = (t[3] + 16384) >> 13;
-    c[7] = (t[4] + 16384) >> 13;
-    c[1] = (t[5] + 16384) >> 13;
-    c[3] = (__mul24(t[6] >> 8, r2) + 8192) >> 12;
-    c[5] = (__mul24(t[7] >> 8, r2) + 8192) >> 12;
-}
-
-// raw px[i*8+j] (kPxBias + value) -> c[u*8+i] (dct_block[u][i])
-__device__ __forceinline__ void fdct_block(const int px[64], int c[64]) {
-    int rows[64];
-#pragma unroll
-    for (int i = 0; i < 8; i++) fdct_row(&px[i * 8], &rows[i * 8]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int col[8];
-        fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], col, i == 0 ? 64 * kPxBias : 0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) c[u * 8 + i] = col[u];
-    }
-}
 
 // Truncating division by the scaled quantiser (image_processing.c:367) as one fp32 multiply by an
 // inflated reciprocal rq = fl((1/d)(1+2^-20)): exact for |n| < 2^15, 1 <= d <= 4150
-// (tests/test_host_tables.py checks every (n, d) pair on the host).
-__device__ __forceinline__ int quant(int n, float rq) { return (int)((float)n * rq); }
+// (tests/test_host_tables.py checks every (n, d) pair on the host).  n arrives as a float holding the integer.
+__device__ __forceinline__ int quant(float n, float rq) { return (int)(n * rq); }
 
 // Where block `bidx` of a strip reads its 64 pixels (encoder.h:275-278 luma, :347-348 chroma).
 // Returns the index of the first pixel and the row stride, both in pixels.
@@ -376,18 +314,26 @@ __device__ __forceinline__ BlockSrc block_source(const Geometry &g, int strip, i
     return s;
 }
 
+// raw pixels of one block -> the 64 quantised levels, natural order q[u*8+i] (BASELINE config 2 kernel)
 template <bool FAST>
 __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint8_t *frame,
                                                    const BlockSrc &s, const float *rq, int q[64]) {
-    int px[64];
+    float rows[64];
     CompCoefF k = comp_coef_f(s.comp);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        load_row<FAST>(frame + (s.first + (long long)i * s.stride) * g.C, g.C, k, &px[i * 8]);
-    int c[64];
-    fdct_block(px, c);
+    for (int i = 0; i < 8; i++) {
+        float px[8];
+        load_row<FAST>(frame + (s.first + (long long)i * s.stride) * g.C, g.C, k, px);
+        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
+    }
 #pragma unroll
-    for (int kk = 0; kk < 64; kk++) q[kk] = quant(c[kk], rq[kk]);
+    for (int i = 0; i < 8; i++) {
+        float c[8];
+        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+#pragma unroll
+        for (int u = 0; u < 8; u++) q[u * 8 + i] = quant(c[u], rq[u * 8 + i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,15 +494,6 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
 
 // ---- pieces shared by the two encode kernels -----------------------------------------------------
 
-// LDS staging of one lane's levels, narrow form: one BYTE per level, four levels per word; word row
-// (u/4)*8 + i holds dct_block[u][i], byte u%4.  Exact whenever no AC level can reach +-128, which the
-// host decides from the quantiser alone (m1v_create: 128 * min AC divisor > the largest |AC coefficient|
-// the FDCT can produce from u8 pixels).  The DC level never goes through the staging (kept in a register).
-__host__ __device__ constexpr int stage_slot8(int p) {
-    int k = scan_inv(p), u = k >> 3, i = k & 7;
-    return ((u >> 2) * 8 + i) * 4 + (u & 3);
-}
-
 // Issue the 8 row loads (8 x 24 B) of one block.
 // Input modes of the dense kernel: 0 = byte loads (4 channels, or a buffer that is not 4-byte aligned),
 // 1 = 3 channels and every block row starts on a 4-byte boundary (width % 8 == 0): 24-byte loads,
@@ -647,15 +584,14 @@ __device__ __forceinline__ void abl_pad(uint32_t &d) {
 
 template <int FAST, bool STAGE8, typename RowT>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
-                                              const RowT raw[8], const float *rq_t, uint32_t *stage, int T,
-                                              int tid, unsigned long long &nz) {
-    int rows[64];
+                                              const RowT raw[8], const float *rq_t, uint32_t *blk, uint32_t &lds_addr) {
+    float rows[64];
     CompCoefF k = comp_coef_f(src.comp);
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        int px[8];
+        float px[8];
         if constexpr (FAST == 3) {
             if (i == 1) { // rows 4..7: requested once row 0 has been consumed
 #pragma unroll
@@ -668,7 +604,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
         } else {
             load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
         }
-        fdct_row(px, &rows[i * 8]);
+        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
 #if M1V_ABL_CLASS
         {
             uint32_t abl; // dead after the padding: no register stays live across rows
@@ -678,44 +614,85 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
 #endif
     }
     int dc = 0;
-    nz = 0;
+    lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blk;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        int c[8], q[8];
-        fdct_col(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                 rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 64 * kPxBias : 0);
+        float c[8];
+        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            q[u] = quant(c[u], rq_t[i * 8 + u]);
-            if (q[u] != 0) nz |= 1ull << scan_pos(u * 8 + i);
-        }
-        if (i == 0) dc = q[0];
-        if (STAGE8) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                // low bytes of four levels -> one word: two v_perm_b32 and an OR
-                uint32_t lo = __builtin_amdgcn_perm((uint32_t)q[4 * h + 1], (uint32_t)q[4 * h], 0x0c0c0400u);
-                uint32_t hi = __builtin_amdgcn_perm((uint32_t)q[4 * h + 3], (uint32_t)q[4 * h + 2], 0x04000c0cu);
-                stage[(h * 8 + i) * T + tid] = lo | hi;
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 4; h++)
-                stage[(h * 8 + i) * T + tid] = ((uint32_t)q[2 * h] & 0xffffu) | ((uint32_t)q[2 * h + 1] << 16);
+            const int q = quant(c[u], rq_t[i * 8 + u]);
+            const int p = scan_pos(u * 8 + i);
+            if (p == 0) dc = q; // the DC level may not fit the staged width: it stays in a register
+            // one LDS byte (halfword) store per level, straight from the converted register: no packing on the vector
+            // ALU.  Inline asm: plain stores are merged back into packed words by the compiler, and volatile ones (or
+            // volatile asm) turn the scalar loads of the quantiser table into per-lane vector loads.  The asm
+            // statements are pure as far as the compiler knows; the address register, passed in-out, chains them (and the
+            // reads of stage_nonzero_mask) in program order.
+            if (STAGE8)
+                asm("ds_write_b8 %0, %1 offset:%2" : "+v"(lds_addr) : "v"(q), "n"(stage_byte8(p)));
+            else
+                asm("ds_write_b16 %0, %1 offset:%2" : "+v"(lds_addr) : "v"(q), "n"(stage_byte16(p)));
         }
     }
     return dc;
 }
 
+// Bit p set = the staged level at zigzag position p is non-zero.  Byte (or halfword) granular "non-zero" flags of a
+// whole word: ((w & 0x7f..) + 0x7f..) | w has the top bit of every non-zero field set; the layout (stage_byte8/16)
+// makes one shift put a word's flags on their zigzag positions.  Position 0 (DC) is the caller's.
 template <bool STAGE8>
-__device__ __forceinline__ int fetch_level(const uint32_t *slot_lut, const uint32_t *stage, int T, int tid, int p) {
-    uint32_t e = (slot_lut[p >> 2] >> ((p & 3) * 8)) & 0xffu;
+__device__ __forceinline__ unsigned long long stage_nonzero_mask(const uint32_t *blk, uint32_t lds_addr) {
+    constexpr int kWords = STAGE8 ? 16 : 32;
+    uint32_t w[kWords];
+    // the staging stores are inline asm (block_to_stage), so the reads are too, chained behind them by lds_addr
+    unsigned long long pr[kWords / 2];
+#pragma unroll
+    for (int j = 0; j < kWords / 2; j += 4)
+        asm("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%7 offset1:%8\n\t"
+            "ds_read2_b32 %2, %4 offset0:%9 offset1:%10\n\tds_read2_b32 %3, %4 offset0:%11 offset1:%12"
+            : "=&v"(pr[j]), "=&v"(pr[j + 1]), "=&v"(pr[j + 2]), "=&v"(pr[j + 3]), "+v"(lds_addr)
+            : "n"(2 * j), "n"(2 * j + 1), "n"(2 * j + 2), "n"(2 * j + 3), "n"(2 * j + 4), "n"(2 * j + 5), "n"(2 * j + 6),
+              "n"(2 * j + 7));
+#pragma unroll
+    for (int j = 0; j < kWords / 2; j += 8)
+        asm("s_waitcnt lgkmcnt(0)"
+            : "+v"(pr[j]), "+v"(pr[j + 1]), "+v"(pr[j + 2]), "+v"(pr[j + 3]), "+v"(pr[j + 4]), "+v"(pr[j + 5]),
+              "+v"(pr[j + 6]), "+v"(pr[j + 7]));
+#pragma unroll
+    for (int j = 0; j < kWords / 2; j++) {
+        w[2 * j] = (uint32_t)pr[j];
+        w[2 * j + 1] = (uint32_t)(pr[j] >> 32);
+    }
+    uint32_t half[2] = {0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (STAGE8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t t = ((w[h * 8 + j] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[h * 8 + j];
+                half[h] |= (t >> (7 - j)) & (0x01010101u << j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t t = ((w[h * 16 + j] & 0x7fff7fffu) + 0x7fff7fffu) | w[h * 16 + j];
+                half[h] |= (t >> (15 - j)) & (0x00010001u << j);
+            }
+        }
+    }
+    return ((unsigned long long)half[1] << 32) | half[0];
+}
+
+template <bool STAGE8>
+__device__ __forceinline__ int fetch_level(const uint32_t *blk, int p) {
     if (STAGE8) {
-        uint32_t w = stage[(e >> 2) * T + tid];
-        return (int)(w << (24 - 8 * (e & 3))) >> 24;
+        const uint32_t w = blk[(p & 7) + 8 * (p >> 5)];
+        return (int)(w << (24 - 8 * ((p >> 3) & 3))) >> 24;
     } else {
-        uint32_t w = stage[(e >> 1) * T + tid];
-        return (e & 1) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
+        const uint32_t w = blk[(p & 15) + 16 * (p >> 5)];
+        return (p & 16) ? ((int)w >> 16) : ((int)(w << 16) >> 16);
     }
 }
 
@@ -797,10 +774,9 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
     const int tid = threadIdx.x;
     uint32_t *ac_lut = lds;                        // kLutWords
     uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
-    uint32_t *slot_lut = dc_lut + kDcWords;        // kSlotWords
-    uint32_t *wave_sums = slot_lut + kSlotWords;   // 32
-    uint32_t *stage = wave_sums + 32;              // 32 x T   (two int16 levels per word)
-    uint32_t *image = stage + 32 * T;              // a.lds_words
+    uint32_t *wave_sums = dc_lut + kDcWords;       // 32
+    uint32_t *stage = wave_sums + 32;              // T blocks x kStageStride16 words (int16 levels)
+    uint32_t *image = stage + kStageStride16 * T;  // a.lds_words
 
     int frame, strip;
     frame_strip_of(blockIdx.x, a.n_frames, g.n_strips, frame, strip);
@@ -818,14 +794,18 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
     }
     for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
     if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
-    if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = a.tab->slot[tid - 32];
     for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
     __syncthreads();
 
     unsigned long long nz = 0;
     int dc = 0;
-    if (valid) dc = block_to_stage<FAST ? 1 : 0, false>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
-    auto fetch = [&](int p) -> int { return fetch_level<false>(slot_lut, stage, T, tid, p); };
+    uint32_t *blk = stage + tid * kStageStride16;
+    if (valid) {
+        uint32_t lds_addr;
+        dc = block_to_stage<FAST ? 1 : 0, false>(g, fbase, src, raw, a.tab->rq_t, blk, lds_addr);
+        nz = (stage_nonzero_mask<false>(blk, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
+    }
+    auto fetch = [&](int p) -> int { return fetch_level<false>(blk, p); };
 
     uint32_t hdr = 0;
     int hlen = 0;
@@ -908,13 +888,12 @@ void k_encode_dense(DenseArgs a) {
     const Geometry &g = a.g;
     const int T = a.threads;
     const int tid = threadIdx.x;
-    constexpr int kStageRows = STAGE8 ? 16 : 32;
+    constexpr int kStride = STAGE8 ? kStageStride8 : kStageStride16;
     uint32_t *ac_lut = lds;                        // kLutWords
     uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
-    uint32_t *slot_lut = dc_lut + kDcWords;        // kSlotWords
-    uint32_t *wave_sums = slot_lut + kSlotWords;   // 32 (16 wave totals, [16] = prefix inside the boundary wave)
-    uint32_t *stage = wave_sums + 32;              // kStageRows x T
-    uint32_t *image = stage + kStageRows * T;      // a.lds_words
+    uint32_t *wave_sums = dc_lut + kDcWords;       // 32 (16 wave totals, [16] = prefix inside the boundary wave)
+    uint32_t *stage = wave_sums + 32;              // T blocks x kStride words
+    uint32_t *image = stage + kStride * T;         // a.lds_words
 
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
@@ -946,11 +925,8 @@ void k_encode_dense(DenseArgs a) {
             lutv[j] = a.tab->ac[min(idx, kLutWords - 1)]; // branch-free: the loads must stay countable (vmcnt)
         }
     }
-    // this lane's word of the DC table (lanes 0..31) or of the staging-slot map (lanes 32..47), one branch-free load
-    const uint32_t *small_src = tid < kDcWords ? &a.tab->dc[tid]
-                                               : (STAGE8 ? &a.tab->slot8[min(tid - 32, kSlotWords - 1)]
-                                                         : &a.tab->slot[min(tid - 32, kSlotWords - 1)]);
-    uint32_t small_tab = *small_src;
+    // this lane's word of the DC table (lanes 0..31), one branch-free load
+    uint32_t small_tab = a.tab->dc[min(tid, kDcWords - 1)];
     // keep the table loads in front of the pixel loads (the scheduler otherwise hoists the pixel loads); a scheduling
     // barrier, not a memory clobber: a clobber would turn the later scalar table loads into vector loads
     __builtin_amdgcn_sched_barrier(0);
@@ -964,7 +940,16 @@ void k_encode_dense(DenseArgs a) {
         const int gbc = min(gb, nb - 1);
         const int strip = gbc / bps;
         src = block_source(g, strip, gbc - strip * bps);
+#if defined(M1V_EXP) && M1V_EXP == 2 // timing experiment (tools/ab.py --nocheck): no pixel loads at all -> what the arithmetic alone costs
+        if constexpr (FAST == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) raw[i].d[k] = (uint32_t)tid * 2654435761u + i * 40503u + k * 9973u + run;
+        }
+#else
         if (FAST) load_block_rows(fbase, src, raw);
+#endif
     }
 
     // ---- workgroup prologue, under the latency of those loads ----
@@ -978,19 +963,27 @@ void k_encode_dense(DenseArgs a) {
         for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
     }
     if (tid < kDcWords) dc_lut[tid] = small_tab;
-    if (tid >= 32 && tid < 32 + kSlotWords) slot_lut[tid - 32] = small_tab;
     for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
     STAMP(0);
 
     unsigned long long nz = 0;
     int dc = 0;
-    if (valid) dc = block_to_stage<FAST, STAGE8, RowT>(g, fbase, src, raw, a.tab->rq_t, stage, T, tid, nz);
+    uint32_t *blk = stage + tid * kStride;
+    if (valid) {
+        uint32_t lds_addr;
+        dc = block_to_stage<FAST, STAGE8, RowT>(g, fbase, src, raw, a.tab->rq_t, blk, lds_addr);
+        nz = (stage_nonzero_mask<STAGE8>(blk, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
+    }
     // The tables and the zeroed image written in the prologue are first read below (dc_header, walk_codes, pass 2);
     // the pixel stage only touches the lane's own staging column, so the waves of the workgroup do not meet before it
     // (+1.6 % over a barrier right after the prologue: no wave waits for the slowest wave's pixel loads).
+#if defined(M1V_EXP) && M1V_EXP == 3 // timing experiment (tools/ab.py --nocheck): pixel stage only, no entropy coding / packing
+    if (valid) slot32[tid] = (uint32_t)nz ^ (uint32_t)(nz >> 32) ^ (uint32_t)dc;
+    return;
+#endif
     __syncthreads();
     STAMP(2);
-    auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(slot_lut, stage, T, tid, p); };
+    auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(blk, p); };
 
     uint32_t hdr = 0;
     int hlen = 0;
@@ -1382,10 +1375,9 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *rgb, int C, unsi
         const uint8_t *q = rgb + i * C;
         uint32_t r = q[0], gg = q[1], b = q[2];
         uint8_t *o = planes + f * 3 * npx_frame;
-        // raw pixel = kPxBias + value and kPxBias's low byte is zero
-        o[p] = (uint8_t)component(r, gg, b, comp_coef_f(0));
-        o[npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(1));
-        o[2 * npx_frame + p] = (uint8_t)component(r, gg, b, comp_coef_f(2));
+        o[p] = (uint8_t)(int)(component_raw(r, gg, b, comp_coef_f(0)) - m1vf::kPxBiasF);
+        o[npx_frame + p] = (uint8_t)(int)(component_raw(r, gg, b, comp_coef_f(1)) - m1vf::kPxBiasF);
+        o[2 * npx_frame + p] = (uint8_t)(int)(component_raw(r, gg, b, comp_coef_f(2)) - m1vf::kPxBiasF);
     }
 }
 
@@ -1552,7 +1544,7 @@ struct m1v_encoder {
     unsigned calls;
     hipStream_t side;
     bool fast_ok;      // geometry allows the 4-byte-aligned 24-byte row loads
-    bool funnel_ok;    // debug switch (m1v_debug_set_input_mode): allow mode 2 (28-byte loads + funnel shift)
+    int forced_mode;   // test hook (m1v_debug_set_input_mode): -1 = pick by geometry and alignment
     Tables *d_tab;
     // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
     // pipelined mode batch k+1 can encode while batch k is still being gathered.
@@ -1716,7 +1708,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     memset(e->batch, 0, sizeof e->batch);
     memset(&e->hp, 0, sizeof e->hp);
     e->fast_ok = channels == 3 && (width % 8) == 0;
-    e->funnel_ok = true;
+    e->forced_mode = -1;
     e->prof = false;
     e->ev_used = 0;
     e->d_stamps = nullptr;
@@ -1736,14 +1728,6 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->narrow = min_ac >= 8;
     build_ac_lut(t->ac);
     build_dc_lut(t->dc);
-    for (int w = 0; w < 16; w++) {
-        uint32_t v = 0;
-        for (int b = 0; b < 4; b++) v |= (uint32_t)stage_slot(4 * w + b) << (8 * b);
-        t->slot[w] = v;
-        uint32_t v8 = 0;
-        for (int b = 0; b < 4; b++) v8 |= (uint32_t)stage_slot8(4 * w + b) << (8 * b);
-        t->slot8[w] = v8;
-    }
     for (int h = 0; h < 256; h++) build_frame_header(t->hdr[h], width, height, h);
 
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
@@ -1830,11 +1814,17 @@ int m1v_set_pipelined(m1v_encoder *e, int enable) {
 int m1v_flush(m1v_encoder *e, void *stream) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
     HIP_TRY(hipSetDevice(e->device));
+    // The mark stays set: a later m1v_encode_device on ANOTHER stream must still wait for this set's gather before its
+    // encode kernel overwrites the scratch (waiting for an event that has completed costs nothing).
     for (m1v_encoder::Batch &bt : e->batch)
-        if (bt.gather_pending) {
-            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, bt.gather_done, 0));
-            bt.gather_pending = false;
-        }
+        if (bt.gather_pending) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, bt.gather_done, 0));
+    return M1V_OK;
+}
+
+int m1v_debug_set_input_mode(m1v_encoder *e, int mode) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    if (mode != -1 && mode != 0 && mode != 2) return fail(M1V_E_ARG, "input mode must be -1 (auto), 0 (byte loads) or 2 (funnel)%s");
+    e->forced_mode = mode;
     return M1V_OK;
 }
 
@@ -1905,10 +1895,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     HIP_TRY(hipSetDevice(e->device));
     m1v_encoder::Batch &bt = e->batch[e->pipelined ? (e->calls++ & 1u) : 0];
     hipStream_t gs = e->pipelined ? e->side : st;   // stream of the layout + gather kernels
-    if (e->pipelined && bt.gather_pending) {         // this set's previous gather must have drained its scratch
+    if (e->pipelined && bt.gather_pending)           // this set's previous gather must have drained its scratch
         HIP_TRY(hipStreamWaitEvent(st, bt.gather_done, 0));
-        bt.gather_pending = false;
-    }
     if (n_frames == 0) {
         if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, 8, st));
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, 4, st));
@@ -1945,15 +1933,16 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.lds_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 1024 : (e->qf <= 50 ? 2048 : 4096));
         a.run_cap = e->run_cap;
         a.stamps = e->d_stamps;
-        const int rows = e->narrow ? 16 : 32;
-        size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + rows * e->dense_T + a.lds_words) * 4;
+        const int stride = e->narrow ? kStageStride8 : kStageStride16;
+        size_t lds = (size_t)(kLutWords + kDcWords + 32 + stride * e->dense_T + a.lds_words) * 4;
         if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
         dim3 grid((unsigned)((size_t)n_frames * e->runs_per_frame)), block((unsigned)e->dense_T);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         // input mode of the pixel loads (see load_block_rows): 1 = aligned rows, 2 = any row offset in an aligned
         // buffer (3 channels), 0 = byte loads
-        const bool aligned4 = ((uintptr_t)d_rgb & 3) == 0 && e->funnel_ok;
-        const int mode = fast ? 1 : (aligned4 && g.C == 3 ? 2 : (aligned4 && g.C == 4 ? 3 : 0));
+        const bool aligned4 = ((uintptr_t)d_rgb & 3) == 0;
+        int mode = fast ? 1 : (aligned4 && g.C == 3 ? 2 : (aligned4 && g.C == 4 ? 3 : 0));
+        if (e->forced_mode == 0 || (e->forced_mode == 2 && mode == 1)) mode = e->forced_mode; // only modes that are valid here
         if (mode == 1 && e->narrow)
             hipLaunchKernelGGL((k_encode_dense<1, true>), grid, block, lds, st, a);
         else if (mode == 1)
@@ -2015,7 +2004,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.threads = e->threads;
         a.lds_words = e->lds_words > 0 ? e->lds_words : kDefaultLdsWords;
         a.stamps = e->d_stamps;
-        size_t lds = (size_t)(kLutWords + kDcWords + kSlotWords + 32 + 32 * e->threads + a.lds_words) * 4;
+        size_t lds = (size_t)(kLutWords + kDcWords + 32 + kStageStride16 * e->threads + a.lds_words) * 4;
         dim3 grid((unsigned)((size_t)n_frames * g.n_strips)), block((unsigned)e->threads);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         if (fast)
@@ -2080,42 +2069,66 @@ long m1v_encode_planes_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, in
     HIP_TRY(ensure_device(&hp.d_out, &hp.out_cap, dcap));
     HIP_TRY(ensure_device(&hp.d_meta, &hp.meta_cap, (size_t)(n_frames + 2) * 8)); // [n] sizes, total, status
     if (planes) HIP_TRY(ensure_device(&hp.d_planes, &hp.planes_cap, frame_planes * n_frames));
-    if (!hp.copy_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&hp.copy_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&hp.work, hipStreamNonBlocking));
-        for (hipEvent_t &ev : hp.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!hp.copy_in) { // all or nothing: a half-built set must not survive into the next call
+        hipError_t err = hipStreamCreateWithFlags(&hp.copy_in, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&hp.work, hipStreamNonBlocking);
+        for (hipEvent_t &ev : hp.uploaded)
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (err != hipSuccess) {
+            if (hp.copy_in) (void)hipStreamDestroy(hp.copy_in);
+            if (hp.work) (void)hipStreamDestroy(hp.work);
+            for (hipEvent_t &ev : hp.uploaded) {
+                if (ev) (void)hipEventDestroy(ev);
+                ev = nullptr;
+            }
+            hp.copy_in = hp.work = nullptr;
+            return fail(M1V_E_HIP, "stream creation failed: %s", hipGetErrorString(err));
+        }
     }
+    // From here on copies to and from the caller's buffers are in flight: every error return first waits for both
+    // streams, so that the caller may free (or reuse) rgb / planes / out as soon as this function has returned.
+    auto drained = [&](int rc) {
+        (void)hipStreamSynchronize(hp.copy_in);
+        (void)hipStreamSynchronize(hp.work);
+        return rc;
+    };
+#define HIP_TRY_DRAIN(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return drained(fail(M1V_E_HIP, #expr ": %s", hipGetErrorString(e_))); \
+    } while (0)
     // copy_in: H2D half A, H2D half B.   work: [planes A -> host] while B uploads, [planes B -> host], encode all.
     const int half[3] = {0, planes && n_frames > 1 ? n_frames / 2 : n_frames, n_frames};
     for (int h = 0; h < 2; h++) {
         int f0 = half[h], nf = half[h + 1] - half[h];
         if (nf == 0) continue;
-        HIP_TRY(hipMemcpyAsync(hp.d_in + frame_in * f0, rgb + frame_in * f0, frame_in * nf, hipMemcpyHostToDevice, hp.copy_in));
-        HIP_TRY(hipEventRecord(hp.uploaded[h], hp.copy_in));
-        HIP_TRY(hipStreamWaitEvent(hp.work, hp.uploaded[h], 0));
+        HIP_TRY_DRAIN(hipMemcpyAsync(hp.d_in + frame_in * f0, rgb + frame_in * f0, frame_in * nf, hipMemcpyHostToDevice, hp.copy_in));
+        HIP_TRY_DRAIN(hipEventRecord(hp.uploaded[h], hp.copy_in));
+        HIP_TRY_DRAIN(hipStreamWaitEvent(hp.work, hp.uploaded[h], 0));
         if (planes) {
             int rc = m1v_convert_device(e, hp.d_in + frame_in * f0, nf, hp.d_planes + frame_planes * f0, hp.work);
-            if (rc != M1V_OK) return rc;
-            HIP_TRY(hipMemcpyAsync(planes + frame_planes * f0, hp.d_planes + frame_planes * f0, frame_planes * nf,
+            if (rc != M1V_OK) return drained(rc);
+            HIP_TRY_DRAIN(hipMemcpyAsync(planes + frame_planes * f0, hp.d_planes + frame_planes * f0, frame_planes * nf,
                                    hipMemcpyDeviceToHost, hp.work));
         }
     }
     int r = m1v_encode_device(e, hp.d_in, n_frames, first_frame_index, hp.d_out, dcap, (uint64_t *)hp.d_meta,
                               (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), hp.work);
-    if (r != M1V_OK) return r;
-    if (m1v_flush(e, hp.work) != M1V_OK) return M1V_E_HIP;
+    if (r != M1V_OK) return drained(r);
+    if (m1v_flush(e, hp.work) != M1V_OK) return drained(M1V_E_HIP);
     std::vector<unsigned long long> meta((size_t)n_frames + 2);
-    HIP_TRY(hipMemcpyAsync(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost, hp.work));
-    HIP_TRY(hipStreamSynchronize(hp.work));
+    HIP_TRY_DRAIN(hipMemcpyAsync(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost, hp.work));
+    HIP_TRY_DRAIN(hipStreamSynchronize(hp.work));
     uint32_t status = (uint32_t)meta[(size_t)n_frames + 1];
     unsigned long long total = meta[n_frames];
     if (status & M1V_STATUS_UNENCODABLE)
         return fail(M1V_E_UNENCODABLE, "an AC level has |level| >= 256 (the reference crashes here)%s");
     if ((status & M1V_STATUS_NOSPACE) || total > out_cap) return fail(M1V_E_NOSPACE, "output buffer too small%s");
-    HIP_TRY(hipMemcpy(out, hp.d_out, total, hipMemcpyDeviceToHost));
+    HIP_TRY_DRAIN(hipMemcpy(out, hp.d_out, total, hipMemcpyDeviceToHost));
     if (frame_sizes)
         for (int f = 0; f < n_frames; f++) frame_sizes[f] = meta[f];
     return (long)total;
+#undef HIP_TRY_DRAIN
 }
 
 long m1v_encode_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, int first_frame_index,

@@ -86,7 +86,10 @@ size_t m1v_file_prolog(uint8_t out[27]);
 
 /* n_frames frames, contiguous in d_rgb (interleaved, width*height*channels bytes each), to
  * contiguous frame records in d_out.  first_frame_index is the global index of frame 0 of the batch
- * (it drives the `hour` fields, encoder.h:42,475-484).
+ * (it drives the `hour` fields, encoder.h:42,475-484).  d_rgb is only read, but a kernel may read up to the next
+ * 4-byte boundary past a row's last byte (three bytes at most, inside the aligned word that holds that byte; pictures
+ * whose width is not a multiple of 8 in a 4-byte aligned buffer): allocations are at least 4-byte granular, so this
+ * never leaves the buffer's last word.
  *   d_frame_sizes  uint64[n_frames] bytes of each record (may be NULL)
  *   d_total        uint64[1] total bytes written (may be NULL)
  *   d_status       uint32[1] OR of M1V_STATUS_* (may be NULL) */
@@ -100,7 +103,9 @@ int m1v_encode_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int 
  * once work enqueued behind m1v_flush(enc, s) on stream s has started; callers double-buffer d_out.  The
  * internal scratch is double-buffered, so at most two batches are in flight. */
 int m1v_set_pipelined(m1v_encoder *enc, int enable);
-/* Makes `stream` wait for every gather still pending on the internal stream. */
+/* Makes `stream` wait for every gather still pending on the internal stream.  An encoder in pipelined mode is meant to
+ * be driven from ONE stream; calls on another stream are still ordered behind the gather that last used their set
+ * of internal buffers. */
 int m1v_flush(m1v_encoder *enc, void *stream);
 
 /* Starts the GPU runtime for `device` (context, code objects) so that a later m1v_create() does not pay for it.
@@ -150,6 +155,10 @@ int m1v_profile_read(m1v_encoder *enc, int *launches, double *total_ms);
 /* Test hook: capacity in 32-bit words of the per-strip LDS bit buffer (0 = default).  A tiny value
  * forces the global-memory fallback path so that tests can cover it. */
 int m1v_debug_set_lds_words(m1v_encoder *enc, int words);
+/* Test hook: force how the dense encode kernel loads its pixels: -1 = automatic (by width, channel count and pointer
+ * alignment), 0 = byte loads (valid everywhere), 2 = 28-byte loads + funnel shift (3 channels, 4-byte aligned buffer).
+ * A mode that is not valid for the buffer at hand is ignored.  Lets tests compare the load paths on one buffer. */
+int m1v_debug_set_input_mode(m1v_encoder *enc, int mode);
 /* Tuning/test hook: blocks per workgroup of the dense encode kernel (multiple of 64, 64..384, not more than
  * the blocks of one strip; 0 = default). */
 int m1v_debug_set_dense_threads(m1v_encoder *enc, int threads);

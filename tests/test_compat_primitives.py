@@ -124,3 +124,135 @@ def test_reference_main_object_links_and_matches(ref, lib, tmp_path):
     assert (tmp_path / "bitstreams" / "awesome_video.mpeg").read_bytes() == (tmp_path / "refbits" / "awesome_video.mpeg").read_bytes()
     for k in (1, 2, 3):
         assert (tmp_path / "bitstreams" / f"image_{k}.bit").read_bytes() == (tmp_path / "refbits" / f"image_{k}.bit").read_bytes()
+
+
+def _bits(bv):
+    n = bv.contents.cap
+    raw = C.string_at(bv.contents.value, (n + 7) // 8)
+    return "".join(f"{x:08b}" for x in raw)[:n]
+
+
+@pytest.mark.reference
+def test_decoder_side_symbols_match_the_reference(ref, lib):
+    """the decoder-side / unused helpers the library exports for link compatibility — DCT, IDCT,
+    fast_IDCT, dequantization, upsampling, insert_8x8_block, subsampling_420, encode_macblk_encoding_value,
+    mpeg1_sequence_end (image_processing.c:157,438,452,492,607,641,114; vlc.c:108; mpeg1_enc.c:96) — against the
+    reference's own shared library (oracle/_ref/libencoder_ref.so) on random inputs, bit for bit."""
+    R = ref.lib()
+    rng = np.random.default_rng(41)
+    vp = C.c_void_p
+
+    def ptr(a):
+        return a.ctypes.data_as(vp)
+
+    # DCT / IDCT: float accumulator updated per term -> bitwise equal floats / bytes
+    blocks = [rng.integers(0, 256, 64, dtype=np.uint8) for _ in range(300)] + [np.full(64, v, np.uint8) for v in (0, 1, 128, 255)]
+    for blk in blocks:
+        a, b = np.zeros(64, np.float32), np.zeros(64, np.float32)
+        lib.DCT(ptr(blk), ptr(a))
+        R.DCT(ptr(blk), ptr(b))
+        assert a.tobytes() == b.tobytes()
+        back_a, back_b = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        lib.IDCT(ptr(a), ptr(back_a))
+        R.IDCT(ptr(b), ptr(back_b))
+        assert np.array_equal(back_a, back_b)
+    for _ in range(300):  # IDCT on coefficients that were never a DCT output (clamping both ways, ties of round())
+        coef = (rng.standard_normal(64) * rng.choice([1.0, 30.0, 400.0])).astype(np.float32)
+        if rng.integers(0, 2):
+            coef = np.round(coef * 2) / 2
+        coef = coef.astype(np.float32)
+        a, b = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        lib.IDCT(ptr(coef), ptr(a))
+        R.IDCT(ptr(coef), ptr(b))
+        assert np.array_equal(a, b)
+
+    # fast_IDCT (the reference's "inverse" re-applies the forward network; pinned as is) and dequantization
+    for _ in range(500):
+        dct = np.round(rng.standard_normal(64) * rng.choice([2.0, 60.0, 900.0])).astype(np.float64)
+        a, b = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        lib.fast_IDCT(ptr(dct), ptr(a))
+        R.fast_IDCT(ptr(dct), ptr(b))
+        assert np.array_equal(a, b)
+        q = rng.integers(-300, 300, 64).astype(np.int32)
+        da, db = np.zeros(64, np.float64), np.zeros(64, np.float64)
+        lib.dequantization(ptr(q), ptr(da))
+        R.dequantization(ptr(q), ptr(db))
+        assert da.tobytes() == db.tobytes()
+
+    # subsampling_420 -> upsampling, even dimensions (the reference reads / leaves gaps out of bounds for odd ones)
+    u8p = C.POINTER(C.c_uint8)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [vp]
+    for (W, H) in ((16, 16), (48, 32), (352, 288)):
+        cb = rng.integers(0, 256, W * H, dtype=np.uint8)
+        cr = rng.integers(0, 256, W * H, dtype=np.uint8)
+        outs = []
+        for L in (lib, R):
+            L.subsampling_420.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p)]
+            L.upsampling.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(u8p), C.POINTER(u8p)]
+            s1, s2, f1, f2 = u8p(), u8p(), u8p(), u8p()
+            L.subsampling_420(ptr(cb), ptr(cr), W, H, C.byref(s1), C.byref(s2))
+            sub = (C.string_at(s1, (W // 2) * (H // 2)), C.string_at(s2, (W // 2) * (H // 2)))
+            L.upsampling(s1, s2, W, H, C.byref(f1), C.byref(f2))
+            outs.append(sub + (C.string_at(f1, W * H), C.string_at(f2, W * H)))
+            for p in (s1, s2, f1, f2):
+                libc.free(p)
+        assert outs[0] == outs[1]
+
+    # insert_8x8_block
+    for _ in range(20):
+        W = int(rng.integers(8, 40))
+        plane_a = rng.integers(0, 256, W * 24, dtype=np.uint8)
+        plane_b = plane_a.copy()
+        blk = rng.integers(0, 256, 64, dtype=np.uint8)
+        x0, y0 = int(rng.integers(0, W - 7)), int(rng.integers(0, 17))
+        lib.insert_8x8_block(ptr(plane_a), W, x0, y0, ptr(blk))
+        R.insert_8x8_block(ptr(plane_b), W, x0, y0, ptr(blk))
+        assert np.array_equal(plane_a, plane_b)
+
+    # motion-vector code words (unused by an I-frame encoder): every value, including the out-of-range NULLs
+    for L in (lib, R):
+        L.encode_macblk_encoding_value.restype = C.POINTER(BitVector)
+        L.encode_macblk_encoding_value.argtypes = [C.c_int]
+    for v in range(-20, 21):
+        a, b = lib.encode_macblk_encoding_value(v), R.encode_macblk_encoding_value(v)
+        assert bool(a) == bool(b)
+        if a:
+            assert _bits(a) == _bits(b) and a.contents.cursor == b.contents.cursor
+
+    a, b = (C.c_uint8 * 4)(), (C.c_uint8 * 4)()
+    lib.mpeg1_sequence_end(a)
+    R.mpeg1_sequence_end(b)
+    assert bytes(a) == bytes(b) == b"\x00\x00\x01\xb7"
+
+
+def test_deliberate_differences_of_the_shim(lib, tmp_path):
+    """What the shim does NOT copy from the reference, asserted so that the list in compat_primitives.c stays true:
+    convert_ycbcr_to_rgb converts the planes it is given (image_processing.c:650 reads the buffer it has just malloc'ed);
+    bitvector_fwrite / bitvector_toarray keep the valid bits of a final partial byte (bit_vector.c:136-144 writes a
+    stale byte); concat_char returns heap memory (mpeg1_enc.c:145 returns a pointer to its own stack frame)."""
+    class Img(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("channels", C.c_int), ("data", C.POINTER(C.c_uint8))]
+    rng = np.random.default_rng(3)
+    W, H = 16, 8
+    Y, Cb, Cr = (rng.integers(0, 256, W * H, dtype=np.uint8) for _ in range(3))
+    img = Img(W, H, 3, None)
+    lib.convert_ycbcr_to_rgb(Y.ctypes.data_as(C.c_void_p), Cb.ctypes.data_as(C.c_void_p), Cr.ctypes.data_as(C.c_void_p), C.byref(img))
+    got = np.frombuffer(C.string_at(img.data, W * H * 3), np.uint8).reshape(-1, 3)
+    y, cb, cr = Y.astype(np.float64), Cb.astype(np.float64) - 128, Cr.astype(np.float64) - 128
+    want = np.stack([np.trunc(y + 1.402 * cr), np.trunc(y - 0.344136 * cb - 0.714136 * cr), np.trunc(y + 1.772 * cb)], 1)
+    assert np.array_equal(got, np.clip(want, 0, 255).astype(np.uint8))
+    C.CDLL(None).free(C.cast(img.data, C.c_void_p))
+
+    lib.bitvector_new.restype = C.POINTER(BitVector)
+    lib.bitvector_new.argtypes = [C.c_char_p, C.c_longlong]
+    bv = lib.bitvector_new(b"1011011101", 16)  # 10 bits: one whole byte + 2 valid bits
+    out = (C.c_char * 4)()
+    lib.bitvector_toarray.argtypes = [C.POINTER(BitVector), C.c_void_p]
+    assert lib.bitvector_toarray(bv, out) == 2 and bytes(out)[:2] == bytes([0b10110111, 0b01000000])
+
+    lib.concat_char.restype = C.c_void_p
+    lib.concat_char.argtypes = [C.c_char_p, C.c_char_p]
+    p = lib.concat_char(b"abcdefgh", b"ijklmnop")
+    assert p and C.string_at(p, 16) == b"abcdefghijklmnop"  # sizeof(char *) = 8 bytes of each, as the reference counts them
+    C.CDLL(None).free(C.c_void_p(p))

@@ -61,3 +61,18 @@ def test_colour_fast_path_proof_over_all_rgb_triples(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", os.path.join(root, "tools", "colour_fast_proof.c"), "-o", exe, "-lm"], check=True)
     p = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "wrong: 0" in p.stdout, p.stdout
+
+
+def test_fp32_fdct_is_exact(tmp_path):
+    """The kernel's FDCT runs in fp32 (ec504_imageencoder_amd/csrc/fdct_f32.h).  tools/fdct_f32_proof.cpp instantiates the
+    same header (a) with a checked number type that computes every add / multiply / fma / floor exactly and fails if any
+    result is not an fp32 value, (b) with float, compared with an integer restatement of image_processing.c:192-307 — on
+    constant blocks, the sign patterns that extremise every linear form of both passes, and 100k random blocks."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fdct_proof")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "ec504_imageencoder_amd", "csrc"),
+                    os.path.join(root, "tools", "fdct_f32_proof.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe, "100000"], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "wrong coefficients 0  inexact operations 0" in p.stdout, p.stdout

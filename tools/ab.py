@@ -16,6 +16,7 @@ ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--n", type=int, default=300)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--nocheck", action="store_true")
 a = ap.parse_args()
 import torch
 
@@ -68,7 +69,7 @@ for r in range(a.rounds + 1):
             digest = hash(out[:tot].cpu().numpy().tobytes())
             if ref is None:
                 ref = (tot, digest)
-            assert (tot, digest) == ref, f"{nm}: output differs from {a.names[0]}"
+            assert a.nocheck or (tot, digest) == ref, f"{nm}: output differs from {a.names[0]}"
 base = statistics.median(times[a.names[0]])
 for nm in a.names:
     t = times[nm]

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "ec504_imageencoder_amd", "csrc", "m1v_kernels.hip")
 out = "/tmp/m1v_marks.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17",
-                "-DM1V_MARKS", "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
+                "-DM1V_MARKS", "-S", "--cuda-device-only", src, "-o", out] + os.environ.get("M1V_DEFS", "").split(),
+               check=True, stderr=subprocess.DEVNULL)
 pat = sys.argv[1] if len(sys.argv) > 1 else "k_encode_stripsILb1ELb0"
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(pat) + r"\S*:", l))
