@@ -56,9 +56,13 @@ namespace {
 // constant geometry
 // ------------------------------------------------------------------------------------------------
 constexpr int kWave = 64;
-constexpr int kAcRows = 32, kAcCols = 40;         // AC lookup: [run-1][|level|-1]
-constexpr int kLutWords = kAcRows * kAcCols;      // 1280
-constexpr int kDcWords = 32;                      // 2 x 9 used
+// VLC table, one private copy per wave in LDS (192 words: a wave fills and reads only its own copy, so the waves of a
+// workgroup need not meet between the pixel stage and the entropy stage):
+//   [0, 32)    per run row r = run - 1:  first entry | entries << 8   (vlc.c:172-174, the offset index)
+//   [32, 142)  the 110 run/level entries in the reference's order, (bits << 16) | code  (vlc.c:176-288)
+//   [144, 153) luma DC size codes, [160, 169) chroma DC size codes              (vlc.c:121-144)
+constexpr int kAcRows = 32;
+constexpr int kVlcRowInfo = 0, kVlcEntries = 32, kVlcDcLuma = 144, kVlcDcChroma = 160, kVlcWords = 192;
 constexpr int kMaxBlockBits = 886;
 constexpr int kDefaultLdsWords = 4096;            // 16 KiB strip image in LDS (strip-per-workgroup kernel)
 
@@ -92,8 +96,7 @@ __host__ __device__ constexpr int stage_byte16(int p) { return ((p & 15) + 16 * 
 struct Tables {
     float rq[64];               // inflated reciprocal of the scaled quantiser, natural order [u][i]
     float rq_t[64];             // the same, transposed [i][u]: one 32-byte scalar load per column pass
-    uint32_t ac[kLutWords];     // (bits << 16) | code, 0 = escape.  [r][idx] with the reference's indexing
-    uint32_t dc[kDcWords];      // [0..8] luma size codes, [16..24] chroma size codes
+    uint32_t vlc[kVlcWords];    // see kVlc*
     uint8_t hdr[256][44];       // PKT SEQ GOP PIC for hour = 0..255, length field zero
 };
 
@@ -226,7 +229,7 @@ struct __attribute__((aligned(4))) Row24 {
 // 8 pixels of one block row (24 or 32 bytes already in registers) -> 8 raw pixels.  One "is any pixel of this row
 // uncertain?" branch per row instead of one per pixel: the branch is taken by about half of the waves, and then only
 // the flagged pixels redo the fp64 expression.
-template <int BPP, typename RowT>
+template <int BPP, bool LEAN, typename RowT>
 __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, float out[8]) {
     auto chan = [&](int j, int ch) -> uint32_t {
         int byte = BPP * j + ch;
@@ -242,12 +245,16 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
     }
     if (lowest < kFracLow) { // rare: redo the row's flagged pixels in the reference's arithmetic
-        // The fractions are recomputed here from the row's bytes (same instructions, same values) instead of being kept
-        // alive across the branch: eight more live registers in the common path would push the kernel over its
-        // 96-VGPR budget.  The empty asm hides the bytes' origin from common-subexpression elimination.
+        // Written as a recomputation from the row's bytes (same instructions, same values); on the main path (aligned
+        // 3-byte pixels) the compiler instead keeps the eight sums alive across the branch (measured 8 % faster than
+        // recomputing: the branch is taken for half of the rows).  The input modes with more raw registers per row (4-byte
+        // pixels, funnel-shifted rows) cannot afford those eight registers inside the 96-VGPR budget (200+ B of scratch
+        // per lane): LEAN hides the bytes' origin behind an empty asm and so forces the recomputation.
         RowT w = v;
+        if constexpr (LEAN) {
 #pragma unroll
-        for (int i = 0; i < (int)(sizeof(RowT) / 4); i++) asm("" : "+v"(w.d[i]));
+            for (int i = 0; i < (int)(sizeof(RowT) / 4); i++) asm("" : "+v"(w.d[i]));
+        }
         auto chan2 = [&](int j, int ch) -> uint32_t {
             int byte = BPP * j + ch;
             return (w.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
@@ -268,7 +275,7 @@ template <bool FAST>
 __device__ __forceinline__ void load_row(const uint8_t *p, int C, const CompCoefF &k, float out[8]) {
     if (FAST) {
         Row24 v = *reinterpret_cast<const Row24 *>(p);
-        convert_row<3>(v, k, out);
+        convert_row<3, false>(v, k, out);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -291,10 +298,10 @@ __device__ __forceinline__ int quant(float n, float rq) { return (int)(n * rq); 
 // Where block `bidx` of a strip reads its 64 pixels (encoder.h:275-278 luma, :347-348 chroma).
 // Returns the index of the first pixel and the row stride, both in pixels.
 struct BlockSrc {
-    long long first;
-    int stride;
-    int comp;   // 0 Y, 1 Cb, 2 Cr
-    int blk;    // 0..5 inside the macroblock
+    uint32_t first;  // 32-bit on purpose (m1v_create rejects frames of 4 GiB and more): a row's address is then a uniform
+    uint32_t stride; // 64-bit frame base + a 32-bit lane offset, which the load instruction adds itself
+    int blk;    // 0..5 inside the macroblock: Y0 Y1 Y2 Y3 Cb Cr
+    __device__ int comp() const { return blk < 4 ? 0 : blk - 3; } // 0 Y, 1 Cb, 2 Cr (derived: one register less to keep)
 };
 __device__ __forceinline__ BlockSrc block_source(const Geometry &g, int strip, int bidx) {
     BlockSrc s;
@@ -303,13 +310,11 @@ __device__ __forceinline__ BlockSrc block_source(const Geometry &g, int strip, i
     if (s.blk < 4) {
         int x0 = strip * 16 + (s.blk & 1) * 8;
         int y0 = mb * 16 + (s.blk >> 1) * 8;
-        s.first = (long long)y0 * g.W + x0;
-        s.stride = g.W;
-        s.comp = 0;
+        s.first = (uint32_t)y0 * (uint32_t)g.W + (uint32_t)x0;
+        s.stride = (uint32_t)g.W;
     } else { // full-resolution Cb/Cr plane addressed with stride W/2 at (x/2, y/2)
-        s.first = (long long)(mb * 8) * g.half_w + strip * 8;
-        s.stride = g.half_w;
-        s.comp = s.blk - 3;
+        s.first = (uint32_t)(mb * 8) * (uint32_t)g.half_w + (uint32_t)(strip * 8);
+        s.stride = (uint32_t)g.half_w;
     }
     return s;
 }
@@ -319,11 +324,11 @@ template <bool FAST>
 __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint8_t *frame,
                                                    const BlockSrc &s, const float *rq, int q[64]) {
     float rows[64];
-    CompCoefF k = comp_coef_f(s.comp);
+    CompCoefF k = comp_coef_f(s.comp());
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float px[8];
-        load_row<FAST>(frame + (s.first + (long long)i * s.stride) * g.C, g.C, k, px);
+        load_row<FAST>(frame + (size_t)((s.first + (uint32_t)i * s.stride) * (uint32_t)g.C), g.C, k, px);
         m1vf::fdct_row_f<float>(px, &rows[i * 8]);
     }
 #pragma unroll
@@ -340,46 +345,76 @@ __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint
 // entropy stage
 // ------------------------------------------------------------------------------------------------
 
-// Walks one block's code words in emission order and hands (code, bits) to `sink`.
-//   hdr/hlen : DC part (mpeg1_blk.c:73-102), with the macroblock header "11" (mpeg1_blk.c:38-51)
-//              in front for block 0
-//   emit     : bit p set = the AC coefficient at zigzag position p is coded.  VLC_encode stops at the
-//              first pair with run 0 (image_processing.c:421): that is the first p >= 1 with both
-//              p-1 and p non-zero.
-// Returns false if a level cannot be coded (vlc.c:349 returns NULL; the reference then segfaults).
-template <typename Fetch, typename Sink>
-__device__ __forceinline__ bool walk_codes(uint32_t hdr, int hlen, bool dc_nonzero,
-                                           unsigned long long emit, const uint32_t *ac_lut,
-                                           Fetch fetch, Sink &sink) {
-    bool ok = true;
-    sink(hdr, hlen);
+// One run/level code word (vlc.c:315-385 with the reference's indexing): r = run - 1 >= 0,
+// level != 0.  Table code when row r holds an entry for |level| - 1 (for r = 0 that is the entry of |level| + 1, and
+// "11" for |level| = 1: the table's first entry is stored as that special case), else the escape "000001" + 6-bit run
+// + 8 or 16 bits of level (vlc.c:346-381); |level| >= 256 cannot be coded (the reference dereferences NULL): `bad`.
+// Branch-free: both table reads use an index that is always valid and the choice is made by selects, so a wave whose
+// lanes disagree executes one instruction stream.  NARROW: |level| < 128 is guaranteed (byte staging).
+template <bool NARROW>
+__device__ __forceinline__ void ac_code(const uint32_t *vlc, int r, int level, uint32_t &code, uint32_t &bits, uint32_t &bad) {
+    const uint32_t L = (uint32_t)(level < 0 ? -level : level);
+    const uint32_t info = vlc[kVlcRowInfo + min(r, kAcRows - 1)];
+    const bool in_table = r < kAcRows && L - 1u < (info >> 8);
+    const uint32_t e = vlc[kVlcEntries + (in_table ? (info & 0xffu) + L - 1u : 0u)];
+    const uint32_t head = (1u << 6) | ((uint32_t)r & 0x3fu); // "000001" + 6-bit run
+    const uint32_t lo = (uint32_t)level & 0xffu;              // (u8)(+L) or (u8)(-L)
+    uint32_t esc = (head << 8) | lo, esc_bits = 20;
+    if (!NARROW) {
+        const bool wide = L >= 128u;
+        esc = wide ? (head << 16) | (level < 0 ? 0x8000u : 0u) | lo : esc;
+        esc_bits = wide ? 28 : 20;
+        bad |= (!in_table && L >= 256u) ? 1u : 0u;
+    }
+    code = in_table ? (e & 0xffffu) : esc;
+    bits = in_table ? (e >> 16) : esc_bits;
+}
+
+// Pass 1 of a block: all its bits in a 64-bit register (when they fit) and their count.
+//   hdr/hlen : DC part (mpeg1_blk.c:73-102), with the macroblock header "11" (mpeg1_blk.c:38-51) in front for
+//              block 0
+//   emit     : bit p set = the AC coefficient at zigzag position p is coded.  VLC_encode stops at the first pair
+//              with run 0 (image_processing.c:421): that is the first p >= 1 with both p-1 and p non-zero.
+// The register simply keeps shifting: if the count ends above 64 its content is meaningless and the block is walked
+// again by pass 2 (walk_codes); no per-code bookkeeping.
+template <bool NARROW, typename Fetch>
+__device__ __forceinline__ void block_bits_pass1(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
+                                                 const uint32_t *vlc, Fetch fetch, unsigned long long &acc, int &tot,
+                                                 uint32_t &bad) {
+    acc = hdr;
+    tot = hlen;
     int prev = dc_nonzero ? 0 : -1;
     while (emit) {
-        int p = __builtin_ctzll(emit);
+        const int p = __builtin_ctzll(emit);
         emit &= emit - 1;
-        int run = p - prev - 1;            // zeros before this coefficient (image_processing.c:716-722)
+        const int r = p - prev - 2; // (zeros before this coefficient, image_processing.c:716-722) - 1, vlc.c:326
         prev = p;
-        int level = fetch(p);
-        int L = level < 0 ? -level : level;
-        int r = run - 1;                   // vlc.c:326
-        uint32_t e = 0;
-        if (r < kAcRows && L <= kAcCols) e = ac_lut[r * kAcCols + (L - 1)];
-        if (e) {
-            sink(e & 0xffffu, (int)(e >> 16));
-        } else {                           // escape, vlc.c:346-381
-            if (L >= 256) ok = false;
-            uint32_t head = (1u << 6) | (uint32_t)(r & 0x3f);    // "000001" + 6-bit run
-            if (L < 128) {
-                sink((head << 8) | ((uint32_t)level & 0xffu), 20);
-            } else {
-                uint32_t lo = (uint32_t)level & 0xffu;           // (u8)(+L) or (u8)(-L)
-                uint32_t hi = level < 0 ? 0x80u : 0x00u;
-                sink((head << 16) | (hi << 8) | lo, 28);
-            }
-        }
+        uint32_t code, bits;
+        ac_code<NARROW>(vlc, r, fetch(p), code, bits, bad);
+        acc = (acc << bits) | code;
+        tot += (int)bits;
     }
-    sink(0x2u, 2); // EOB "10", mpeg1_blk.c:115-117
-    return ok;
+    acc = (acc << 2) | 0x2u; // EOB "10", mpeg1_blk.c:115-117
+    tot += 2;
+}
+
+// The same walk, code word by code word into `sink` (pass 2 of the rare blocks that exceed 64 bits).
+template <bool NARROW, typename Fetch, typename Sink>
+__device__ __forceinline__ void walk_codes(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
+                                           const uint32_t *vlc, Fetch fetch, Sink &sink) {
+    sink(hdr, hlen);
+    int prev = dc_nonzero ? 0 : -1;
+    uint32_t bad = 0;
+    while (emit) {
+        const int p = __builtin_ctzll(emit);
+        emit &= emit - 1;
+        const int r = p - prev - 2;
+        prev = p;
+        uint32_t code, bits;
+        ac_code<NARROW>(vlc, r, fetch(p), code, bits, bad);
+        sink(code, (int)bits);
+    }
+    sink(0x2u, 2);
 }
 
 // MSB-first OR of `bits` code bits at absolute bit position `pos` of a zero-initialised word image.
@@ -505,7 +540,7 @@ struct __attribute__((aligned(4))) Row28 {
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row28 raw[8]) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint8_t *p = fbase + (src.first + (long long)i * src.stride) * 3;
+        const uint8_t *p = fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u);
         const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
         const uint32_t *q = reinterpret_cast<const uint32_t *>(p - m);
 #pragma unroll
@@ -523,7 +558,7 @@ struct __attribute__((aligned(4))) Row32 {
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row32 raw[8]) {
 #pragma unroll
     for (int i = 0; i < 4; i++)
-        raw[i] = *reinterpret_cast<const Row32 *>(fbase + (src.first + (long long)i * src.stride) * 4);
+        raw[i] = *reinterpret_cast<const Row32 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 4u));
 }
 __device__ __forceinline__ Row24 row_bytes(const Row24 &v, const uint8_t *) { return v; }
 __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
@@ -536,7 +571,7 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        raw[i] = *reinterpret_cast<const Row24 *>(fbase + (src.first + (long long)i * src.stride) * 3);
+        raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
 }
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
@@ -586,7 +621,7 @@ template <int FAST, bool STAGE8, typename RowT>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
                                               const RowT raw[8], const float *rq_t, uint32_t *blk, uint32_t &lds_addr) {
     float rows[64];
-    CompCoefF k = comp_coef_f(src.comp);
+    CompCoefF k = comp_coef_f(src.comp());
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
 #pragma unroll
@@ -596,13 +631,13 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
             if (i == 1) { // rows 4..7: requested once row 0 has been consumed
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    late[r] = *reinterpret_cast<const Row32 *>(fbase + (src.first + (long long)(r + 4) * src.stride) * 4);
+                    late[r] = *reinterpret_cast<const Row32 *>(fbase + (size_t)((src.first + (uint32_t)(r + 4) * src.stride) * 4u));
             }
-            convert_row<4>(i < 4 ? raw[i] : late[i - 4], k, px);
+            convert_row<4, true>(i < 4 ? raw[i] : late[i - 4], k, px);
         } else if constexpr (FAST != 0) {
-            convert_row<3>(row_bytes(raw[i], fbase + (src.first + (long long)i * src.stride) * 3), k, px);
+            convert_row<3, FAST == 2>(row_bytes(raw[i], fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u)), k, px);
         } else {
-            load_row<false>(fbase + (src.first + (long long)i * src.stride) * g.C, g.C, k, px);
+            load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
         m1vf::fdct_row_f<float>(px, &rows[i * 8]);
 #if M1V_ABL_CLASS
@@ -698,13 +733,13 @@ __device__ __forceinline__ int fetch_level(const uint32_t *blk, int p) {
 
 // DC part of a block (mpeg1_blk.c:73-102) with the macroblock header "11" (mpeg1_blk.c:38-51) in front
 // for block 0 of a macroblock.
-__device__ __forceinline__ void dc_header(int dc, bool luma, int blk, const uint32_t *dc_lut, uint32_t &hdr,
+__device__ __forceinline__ void dc_header(int dc, bool luma, int blk, const uint32_t *vlc, uint32_t &hdr,
                                           int &hlen) {
     if (dc != 0) {
         int coe = dc < 0 ? -dc : dc;
         int low = coe & 0xff;
         int sz = low ? 32 - __builtin_clz((unsigned)low) : 1;
-        uint32_t e = dc_lut[(luma ? 0 : 16) + sz];
+        uint32_t e = vlc[(luma ? kVlcDcLuma : kVlcDcChroma) + sz];
         if (dc < 0) coe ^= 1 << (sz - 1);
         hdr = ((e & 0xffffu) << sz) | ((uint32_t)coe & 0xffu & ((1u << sz) - 1u));
         hlen = (int)(e >> 16) + sz;
@@ -728,16 +763,16 @@ __device__ __forceinline__ unsigned long long emit_set(unsigned long long nz) {
 // One lane's block bits: the first 64 in a register (the common case is the whole block), the count always.
 struct BlockBits {
     unsigned long long acc;
-    int nacc, tot;
-    bool spilled;
+    int tot;
+    __device__ bool spilled() const { return tot > 64; }
 };
 
 // OR a block's bits into a zeroed word image at bit offset `off` (LDS image: logical big-endian words;
 // global image: byte-swapped so that memory is already the byte stream).
 template <bool GLOBAL, typename Walk>
 __device__ __forceinline__ void put_block(uint32_t *img, uint32_t off, const BlockBits &b, Walk walk) {
-    if (!b.spilled) {
-        unsigned long long A = b.acc << (64 - b.nacc);
+    if (!b.spilled()) {
+        unsigned long long A = b.acc << (64 - b.tot);
         uint32_t w = off >> 5, sh = off & 31u;
         uint32_t w0 = (uint32_t)(A >> (32 + sh));
         uint32_t w1 = (uint32_t)(A >> sh);
@@ -772,9 +807,8 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
     const Geometry &g = a.g;
     const int T = a.threads; // == 64
     const int tid = threadIdx.x;
-    uint32_t *ac_lut = lds;                        // kLutWords
-    uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
-    uint32_t *wave_sums = dc_lut + kDcWords;       // 32
+    uint32_t *vlc = lds;                           // kVlcWords (one wave)
+    uint32_t *wave_sums = vlc + kVlcWords;         // 32
     uint32_t *stage = wave_sums + 32;              // T blocks x kStageStride16 words (int16 levels)
     uint32_t *image = stage + kStageStride16 * T;  // a.lds_words
 
@@ -792,8 +826,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
         src = block_source(g, strip, tid);
         if (FAST) load_block_rows(fbase, src, raw);
     }
-    for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
-    if (tid < kDcWords) dc_lut[tid] = a.tab->dc[tid];
+    for (int i = tid; i < kVlcWords; i += T) vlc[i] = a.tab->vlc[i];
     for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
     __syncthreads();
 
@@ -807,24 +840,14 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
     }
     auto fetch = [&](int p) -> int { return fetch_level<false>(blk, p); };
 
-    uint32_t hdr = 0;
+    uint32_t hdr = 0, bad = 0;
     int hlen = 0;
     unsigned long long emit = 0;
-    BlockBits bb = {0, 0, 0, false};
-    bool ok = true;
+    BlockBits bb = {0, 0};
     if (valid) {
-        dc_header(dc, src.comp == 0, src.blk, dc_lut, hdr, hlen);
+        dc_header(dc, src.blk < 4, src.blk, vlc, hdr, hlen);
         emit = emit_set(nz);
-        auto sink = [&](uint32_t code, int bits) {
-            bb.tot += bits;
-            if (!bb.spilled && bb.nacc + bits <= 64) {
-                bb.acc = (bb.acc << bits) | code;
-                bb.nacc += bits;
-            } else {
-                bb.spilled = true;
-            }
-        };
-        ok = walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
+        block_bits_pass1<false>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
     }
     uint32_t strip_bits;
     uint32_t off = block_scan_exclusive_1b((uint32_t)bb.tot, wave_sums, 0, T, strip_bits) + 38;
@@ -843,7 +866,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
         atomicOr(&img[1], global_mode ? __builtin_bswap32(h1) : h1);
     }
     if (valid) {
-        auto walk = [&](auto &sink) { walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink); };
+        auto walk = [&](auto &sink) { walk_codes<false>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
         if (global_mode)
             put_block<true>(slot32, off, bb, walk);
         else
@@ -856,7 +879,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
         for (uint32_t i = tid; i < nwords; i += T) slot32[i] = __builtin_bswap32(image[i]);
     }
     if (tid == 0) a.strip_bytes[(unsigned long long)frame * g.n_strips + strip] = (end_bits + 7) >> 3;
-    if (!ok) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+    if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
 }
 
 // ---- kernel 2 (the dominant one): dense runs of blocks -----------------------------------------------
@@ -876,7 +899,8 @@ struct DenseArgs {
     int n_frames;
     int threads;            // T
     int runs_per_frame;
-    int lds_words;
+    int lds_words;          // capacity of the LDS image of the run's bits
+    int zero_iters;         // ceil(lds_words / T): rounds of T words that clear it
     uint32_t run_cap;       // bytes per scratch slot
     unsigned long long *stamps;
 };
@@ -889,9 +913,10 @@ void k_encode_dense(DenseArgs a) {
     const int T = a.threads;
     const int tid = threadIdx.x;
     constexpr int kStride = STAGE8 ? kStageStride8 : kStageStride16;
-    uint32_t *ac_lut = lds;                        // kLutWords
-    uint32_t *dc_lut = ac_lut + kLutWords;         // kDcWords
-    uint32_t *wave_sums = dc_lut + kDcWords;       // 32 (16 wave totals, [16] = prefix inside the boundary wave)
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *vlc = lds + wave * kVlcWords;        // this wave's private copy of the VLC table
+    uint32_t *wave_sums = lds + (T >> 6) * kVlcWords; // 32 (16 wave totals, [16] = prefix inside the boundary wave)
     uint32_t *stage = wave_sums + 32;              // T blocks x kStride words
     uint32_t *image = stage + kStride * T;         // a.lds_words
 
@@ -915,18 +940,9 @@ void k_encode_dense(DenseArgs a) {
 
     // ---- table loads first, then every pixel load of this lane's block: the in-order vmcnt lets the
     //      tables be consumed while the pixels are still in flight ----
-    constexpr int kLutRegs = 5; // T >= 256 covers the 1280 words
-    uint32_t lutv[kLutRegs];
-    const bool lut_in_regs = T * kLutRegs >= kLutWords;
-    if (lut_in_regs) {
+    uint32_t vlcv[kVlcWords / kWave];
 #pragma unroll
-        for (int j = 0; j < kLutRegs; j++) {
-            int idx = tid + j * T;
-            lutv[j] = a.tab->ac[min(idx, kLutWords - 1)]; // branch-free: the loads must stay countable (vmcnt)
-        }
-    }
-    // this lane's word of the DC table (lanes 0..31), one branch-free load
-    uint32_t small_tab = a.tab->dc[min(tid, kDcWords - 1)];
+    for (int j = 0; j < kVlcWords / kWave; j++) vlcv[j] = a.tab->vlc[lane + j * kWave];
     // keep the table loads in front of the pixel loads (the scheduler otherwise hoists the pixel loads); a scheduling
     // barrier, not a memory clobber: a clobber would turn the later scalar table loads into vector loads
     __builtin_amdgcn_sched_barrier(0);
@@ -937,9 +953,11 @@ void k_encode_dense(DenseArgs a) {
     using RowT = typename std::conditional<FAST == 3, Row32, typename std::conditional<FAST == 2, Row28, Row24>::type>::type;
     RowT raw[8];
     {
-        const int gbc = min(gb, nb - 1);
-        const int strip = gbc / bps;
-        src = block_source(g, strip, gbc - strip * bps);
+        // a run touches at most two strips (T <= blocks per strip), so the lane's strip needs no division; lanes past the
+        // end of the frame (last run only) re-load the frame's last block
+        const int strip = valid ? s0 + (in_b ? 1 : 0) : g.n_strips - 1;
+        const int bidx = valid ? (in_b ? tid - nA : pos0 + tid) : bps - 1;
+        src = block_source(g, strip, bidx);
 #if defined(M1V_EXP) && M1V_EXP == 2 // timing experiment (tools/ab.py --nocheck): no pixel loads at all -> what the arithmetic alone costs
         if constexpr (FAST == 1) {
 #pragma unroll
@@ -953,17 +971,10 @@ void k_encode_dense(DenseArgs a) {
     }
 
     // ---- workgroup prologue, under the latency of those loads ----
-    if (lut_in_regs) {
 #pragma unroll
-        for (int j = 0; j < kLutRegs; j++) {
-            int idx = tid + j * T;
-            if (idx < kLutWords) ac_lut[idx] = lutv[j];
-        }
-    } else {
-        for (int i = tid; i < kLutWords; i += T) ac_lut[i] = a.tab->ac[i];
-    }
-    if (tid < kDcWords) dc_lut[tid] = small_tab;
-    for (int i = tid; i < a.lds_words; i += T) image[i] = 0;
+    for (int j = 0; j < kVlcWords / kWave; j++) vlc[lane + j * kWave] = vlcv[j];
+#pragma unroll 1
+    for (int k = 0; k < a.zero_iters; k++) image[k * T + tid] = 0; // the allocation is rounded up to a multiple of T words
     STAMP(0);
 
     unsigned long long nz = 0;
@@ -974,41 +985,27 @@ void k_encode_dense(DenseArgs a) {
         dc = block_to_stage<FAST, STAGE8, RowT>(g, fbase, src, raw, a.tab->rq_t, blk, lds_addr);
         nz = (stage_nonzero_mask<STAGE8>(blk, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
     }
-    // The tables and the zeroed image written in the prologue are first read below (dc_header, walk_codes, pass 2);
-    // the pixel stage only touches the lane's own staging column, so the waves of the workgroup do not meet before it
-    // (+1.6 % over a barrier right after the prologue: no wave waits for the slowest wave's pixel loads).
+    // No barrier here: pass 1 below reads only the lane's own staged levels and the wave's own copy of the VLC table.
+    // The image zeroed in the prologue is first touched in pass 2, behind the barrier of the scan.
 #if defined(M1V_EXP) && M1V_EXP == 3 // timing experiment (tools/ab.py --nocheck): pixel stage only, no entropy coding / packing
     if (valid) slot32[tid] = (uint32_t)nz ^ (uint32_t)(nz >> 32) ^ (uint32_t)dc;
     return;
 #endif
-    __syncthreads();
     STAMP(2);
     auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(blk, p); };
 
-    uint32_t hdr = 0;
+    uint32_t hdr = 0, bad = 0;
     int hlen = 0;
     unsigned long long emit = 0;
-    BlockBits bb = {0, 0, 0, false};
-    bool ok = true;
+    BlockBits bb = {0, 0};
     if (valid) {
-        dc_header(dc, src.comp == 0, src.blk, dc_lut, hdr, hlen);
+        dc_header(dc, src.blk < 4, src.blk, vlc, hdr, hlen);
         emit = emit_set(nz);
-        auto sink = [&](uint32_t code, int bits) {
-            bb.tot += bits;
-            if (!bb.spilled && bb.nacc + bits <= 64) {
-                bb.acc = (bb.acc << bits) | code;
-                bb.nacc += bits;
-            } else {
-                bb.spilled = true;
-            }
-        };
-        ok = walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink);
+        block_bits_pass1<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
     }
     STAMP(4);
 
     // ---- exclusive scan of the bit counts; PA = bits of segment 0's blocks ----
-    const int lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t incl = wave_scan_inclusive((uint32_t)bb.tot);
     if (lane == kWave - 1) wave_sums[wave] = incl;
     if (tid == nA - 1) wave_sums[16] = incl;       // prefix inside the wave that holds segment 0's last lane
@@ -1055,7 +1052,7 @@ void k_encode_dense(DenseArgs a) {
         m[2] = base1;
     }
     if (valid) {
-        auto walk = [&](auto &sink) { walk_codes(hdr, hlen, dc != 0, emit, ac_lut, fetch, sink); };
+        auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
         if (global_mode)
             put_block<true>(slot32, off, bb, walk);
         else
@@ -1066,7 +1063,7 @@ void k_encode_dense(DenseArgs a) {
     STAMP(7);
     if (!global_mode)
         for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
-    if (!ok) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+    if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
     STAMP(8);
 }
 
@@ -1450,10 +1447,11 @@ void scaled_matrix(int qf, int q[64]) {
     }
 }
 
-// Run/level code words without sign bit as the reference stores them (vlc.c:176-288), expanded to
-// the [run-1][|level|-1] lookup its indexing rule produces (vlc.c:329-339): row 0 is shifted by one
-// level (entry idx codes level idx+2) except idx 0 which is the special "11".
-void build_ac_lut(uint32_t lut[kLutWords]) {
+// The VLC table of the kernels (layout: kVlc*).  Run/level code words without sign bit as the reference stores them
+// (vlc.c:176-288), in its order, with its offset index (vlc.c:172-174); the reference's indexing rule (vlc.c:329-339)
+// reads row r = run - 1 at |level| - 1, so in row 0 entry idx codes level idx + 2 — except idx 0, which the rule
+// replaces by the special "11" and which is therefore stored that way here.  DC size codes: vlc.c:121-144.
+void build_vlc_table(uint32_t t[kVlcWords]) {
     static const unsigned char row_len[32] = {39, 18, 5, 4, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2,
                                               2,  1,  1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     static const unsigned char code[110] = {
@@ -1470,27 +1468,21 @@ void build_ac_lut(uint32_t lut[kLutWords]) {
         13, 13, 15, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 4,  7,  10, 12, 13, 5,  8,  12, 13,
         5,  10, 12, 6,  10, 13, 6,  12, 16, 6,  12, 7,  12, 7,  13, 8,  13, 8,  16, 8,  16, 8,
         16, 10, 16, 10, 16, 10, 15, 12, 12, 12, 12, 12, 13, 13, 13, 13, 13, 16, 16, 16, 16, 16};
-    memset(lut, 0, kLutWords * sizeof(uint32_t));
+    memset(t, 0, kVlcWords * sizeof(uint32_t));
     int first = 0;
-    for (int r = 0; r < 32; r++) {
-        for (int idx = 0; idx < row_len[r]; idx++) {
-            int e = first + idx;
-            lut[r * kAcCols + idx] = ((uint32_t)bits[e] << 16) | code[e];
-        }
+    for (int r = 0; r < kAcRows; r++) {
+        t[kVlcRowInfo + r] = (uint32_t)first | ((uint32_t)row_len[r] << 8);
         first += row_len[r];
     }
-    lut[0] = (2u << 16) | 0x3u; // run 1, |level| 1 -> "11" (vlc.c:329-334 with first == 0)
-}
-
-void build_dc_lut(uint32_t dc[kDcWords]) { // vlc.c:121-144
+    for (int e = 0; e < 110; e++) t[kVlcEntries + e] = ((uint32_t)bits[e] << 16) | code[e];
+    t[kVlcEntries] = (2u << 16) | 0x3u; // run 1, |level| 1 -> "11" (vlc.c:329-334 with first == 0)
     static const unsigned char lc[9] = {0x4, 0x0, 0x1, 0x5, 0x6, 0xE, 0x1E, 0x3E, 0x7E};
     static const unsigned char lb[9] = {3, 2, 2, 3, 3, 4, 5, 6, 7};
     static const unsigned char cc[9] = {0x0, 0x1, 0x2, 0x6, 0xE, 0x1E, 0x3E, 0x7E, 0xFE};
     static const unsigned char cb[9] = {2, 2, 2, 3, 4, 5, 6, 7, 8};
-    memset(dc, 0, kDcWords * sizeof(uint32_t));
     for (int i = 0; i < 9; i++) {
-        dc[i] = ((uint32_t)lb[i] << 16) | lc[i];
-        dc[16 + i] = ((uint32_t)cb[i] << 16) | cc[i];
+        t[kVlcDcLuma + i] = ((uint32_t)lb[i] << 16) | lc[i];
+        t[kVlcDcChroma + i] = ((uint32_t)cb[i] << 16) | cc[i];
     }
 }
 
@@ -1679,6 +1671,8 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (xe > width || ye > height)
         return fail(M1V_E_ARG, "picture smaller than the 96x144 region the reference encodes%s");
     if (xe == 0 || ye == 0) return fail(M1V_E_ARG, "picture smaller than one macroblock%s");
+    if ((unsigned long long)width * height * channels >= (1ull << 32))
+        return fail(M1V_E_ARG, "a frame of 4 GiB or more (byte offsets inside a frame are 32-bit)%s");
     int n = m1v_device_count();
     if (n <= 0) return fail(M1V_E_NODEVICE, "no HIP device%s");
     if (device < 0 || device >= n) return fail(M1V_E_ARG, "device index out of range%s");
@@ -1726,8 +1720,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     int min_ac = q[1];
     for (int k = 1; k < 64; k++) min_ac = q[k] < min_ac ? q[k] : min_ac;
     e->narrow = min_ac >= 8;
-    build_ac_lut(t->ac);
-    build_dc_lut(t->dc);
+    build_vlc_table(t->vlc);
     for (int h = 0; h < 256; h++) build_frame_header(t->hdr[h], width, height, h);
 
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
@@ -1934,7 +1927,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.run_cap = e->run_cap;
         a.stamps = e->d_stamps;
         const int stride = e->narrow ? kStageStride8 : kStageStride16;
-        size_t lds = (size_t)(kLutWords + kDcWords + 32 + stride * e->dense_T + a.lds_words) * 4;
+        a.zero_iters = (a.lds_words + e->dense_T - 1) / e->dense_T;
+        size_t lds = (size_t)((e->dense_T / kWave) * kVlcWords + 32 + stride * e->dense_T + a.zero_iters * e->dense_T) * 4;
         if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
         dim3 grid((unsigned)((size_t)n_frames * e->runs_per_frame)), block((unsigned)e->dense_T);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
@@ -2004,7 +1998,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.threads = e->threads;
         a.lds_words = e->lds_words > 0 ? e->lds_words : kDefaultLdsWords;
         a.stamps = e->d_stamps;
-        size_t lds = (size_t)(kLutWords + kDcWords + 32 + kStageStride16 * e->threads + a.lds_words) * 4;
+        size_t lds = (size_t)(kVlcWords + 32 + kStageStride16 * e->threads + a.lds_words) * 4;
         dim3 grid((unsigned)((size_t)n_frames * g.n_strips)), block((unsigned)e->threads);
         if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
         if (fast)
