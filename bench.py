@@ -22,41 +22,97 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(W, H, qf, seed, gpu_head=None, budget_s=12.0):
-    """The oracle (CPU restatement, 1 thread = the reference's execution model) timed on a bounded sample of the
-    same workload.  This leg is the only place bench.py touches oracle/: besides the timing it checks, outside the
-    timed GPU region, that the GPU's first frame records (gpu_head: bytes) equal the oracle's for the same frames."""
+def _host_cpu():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def cpu_baseline(W, H, qf, seed, gpu_head=None, budget_s=10.0):
+    """The oracle (CPU restatement of the reference's path, oracle/mpeg1_oracle.c) timed on bounded samples of the same
+    workload, on this box's host cores.  This leg is the only place bench.py touches oracle/: besides the timing it
+    checks, outside the timed GPU region, that the GPU's first frame records (gpu_head: bytes) equal the oracle's.
+      value / cores = 1   one thread, FULL region: the reference's execution model (it is single-threaded)
+      strict              one thread, the 96x144 region the UNMODIFIED reference encodes (colour-converts the whole
+                          frame, codes 54 macroblocks)
+      threads             frame-parallel oracle on all usable host cores: what the host could do, labelled as such"""
     import oracle_ffi as orc
-    chunk, n, dt, verified = 16, 0, 0.0, None
-    while dt < budget_s and n < 4096:       # bounded sample, generated chunk-wise to bound host memory
-        frames = orc.synth_frames(chunk, W, H, seed=seed, first_index=n)
-        t0 = time.perf_counter()
-        body, sizes = orc.encode_frames(frames, chunk, W, H, n, qf, orc.MODE_FULL, threads=1)
-        dt += time.perf_counter() - t0
-        if n == 0 and gpu_head is not None:
-            k = int(sizes[0] + sizes[1])
-            verified = bool(gpu_head[:k] == body[:k])
-        n += chunk
-    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{n} x {W}x{H} synthetic frames, FULL region, qf {qf}, oracle/mpeg1_oracle.c single thread, {dt:.1f} s"}
+    model, online, usable = _host_cpu()
+
+    def timed(mode, threads, budget, chunk):
+        n, dt, verified = 0, 0.0, None
+        while dt < budget and n < 8192:     # bounded sample, generated chunk-wise to bound host memory
+            frames = orc.synth_frames(chunk, W, H, seed=seed, first_index=n)
+            t0 = time.perf_counter()
+            body, sizes = orc.encode_frames(frames, chunk, W, H, n, qf, mode, threads=threads)
+            dt += time.perf_counter() - t0
+            if n == 0 and gpu_head is not None and mode == orc.MODE_FULL:
+                k = int(sizes[0] + sizes[1])
+                verified = bool(gpu_head[:k] == body[:k])
+            n += chunk
+        return n, dt, verified
+
+    n1, t1, verified = timed(orc.MODE_FULL, 1, budget_s, 16)
+    ns, ts, _ = timed(orc.MODE_STRICT, 1, budget_s / 4, 16)
+    nt_threads = max(1, min(usable, 64))
+    nt, tt, _ = timed(orc.MODE_FULL, nt_threads, budget_s / 2, 4 * nt_threads)
+    out = {"value": round(n1 / t1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n1} x {W}x{H} synthetic frames, FULL region, qf {qf}, oracle/mpeg1_oracle.c single thread, {t1:.1f} s",
+           "host": {"cpu": model, "cores_online": online, "cores_usable": usable},
+           "build": "gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile); the reference's own Makefile uses -g without -O",
+           "strict": {"value": round(ns / ts, 3), "unit": "frames/s", "cores": 1,
+                      "sample": f"{ns} frames, the 96x144 region of the unmodified reference, {ts:.1f} s"},
+           "threads": {"value": round(nt / tt, 3), "unit": "frames/s", "cores": nt_threads,
+                       "sample": f"{nt} frames, FULL region, frame-parallel on {nt_threads} threads, {tt:.1f} s"}}
     if verified is not None:
         out["gpu_output_matches_oracle"] = verified
     return out
 
 
-def pmc_traffic(W, H, n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json, written from tools/pmc.sh output): (2 x FETCH_SIZE + WRITE_SIZE) KiB — on
-    gfx950 FETCH_SIZE counts half of the bytes of wide reads (MI355X_MICROARCH.md, HBM section).  PMC cannot be
-    collected from inside this process, so this is the committed measurement of the same workload, or null."""
+def _committed_pmc(W, H, n):
+    """The committed rocprofv3 PMC record of this workload on the shipped kernel (profiles/r02_pmc.json, written by
+    tools/pmc_record.py from the CSVs of tools/pmc.sh), or None.  PMC cannot be collected from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            rec = json.load(f)
-        if [rec["width"], rec["height"], rec["frames"]] == [W, H, n]:
-            return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024)
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            for rec in json.load(f)["workloads"]:
+                if [rec["width"], rec["height"], rec["frames"]] == [W, H, n]:
+                    return rec
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def pmc_traffic(rec):
+    """HBM bytes per launch of the dominant kernel: (2 x FETCH_SIZE + WRITE_SIZE) KiB — on gfx950 FETCH_SIZE counts half
+    of the bytes of wide reads (MI355X_MICROARCH.md, HBM section)."""
+    return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024) if rec else None
+
+
+def valu_roofline(rec, kernel_ms):
+    """The resource that actually binds the dominant kernel (profiles/r02_*: without its pixel loads the kernel runs only
+    ~10 % faster): vector-ALU issue.  achieved = (vector instructions per launch, PMC) x (issue cycles per instruction,
+    weighted over the kernel's static class mix with the per-class costs measured by tools/ubench) / live kernel time;
+    peak = SIMDs x shader clock under this load (PMC: GRBM_GUI_ACTIVE / 8 / kernel time of the same pass)."""
+    if not rec or "valu" not in rec or kernel_ms <= 0:
+        return None
+    v = rec["valu"]
+    issue_cycles = v["insts_per_launch"] * v["issue_cycles_per_inst"]
+    peak = v["simds"] * v["clock_ghz"] * 1e9
+    achieved = issue_cycles / (kernel_ms * 1e-3)
+    return {"bound": "valu-issue", "achieved": round(achieved / 1e12, 4), "peak": round(peak / 1e12, 4),
+            "unit": "T issue-cycles/s", "frac": round(achieved / peak, 4), "insts_per_launch": v["insts_per_launch"],
+            "issue_cycles_per_inst": v["issue_cycles_per_inst"], "clock_ghz": v["clock_ghz"], "source": v.get("source", "")}
 
 
 def cli_bench(args):
@@ -111,7 +167,7 @@ def cli_bench(args):
             res[tag] = {"seconds": round(best, 3), "frames_per_s": round(n / best, 1)}
         line = {"metric": f"{W}x{H} JPEG folder -> .mpeg + .bit, frames/s (whole CLI process, end to end)",
                 "value": res["default"]["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
-                "data": "synthetic", "dtype": "int32 (FDCT/VLC) + f64 (colour)", "vs_baseline": None,
+                "data": "synthetic", "dtype": "f32 (colour fast path, FDCT) + f64 (colour ties) + int32 (VLC, packing)", "vs_baseline": None,
                 "config": {"workload": f"{n} JPEG files {W}x{H} (quality 90, {jpeg_bytes / n / 1e3:.0f} KB each) in {os.path.dirname(d)}, "
                                        f"FULL region, quality_factor {qf}, ./encoder = tools/encoder_cli.c + libencoder.so",
                            "host_threads": os.cpu_count(), "runs": res}}
@@ -151,6 +207,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 code path on a box with ONE GPU: every rank encodes on cuda:0, "
                          "the bitstream gather goes through host memory (numbers are not meaningful)")
+    ap.add_argument("--gather", default="xgmi", choices=["xgmi", "host"],
+                    help="N>1: how the per-rank bitstreams reach one place.  xgmi = grouped send/recv to rank 0 (RCCL); "
+                         "host = every rank copies its blob into its slice of one pinned host buffer shared by the ranks")
     ap.add_argument("--cli", action="store_true",
                     help="instead of the headline run: time the folder-of-JPEGs CLI path end to end (SURVEY 8f.1/8f.2)")
     ap.add_argument("--cli-reference-frames", type=int, default=6)
@@ -165,7 +224,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ec504_imageencoder_amd import Mpeg1Encoder
-    from ec504_imageencoder_amd.sharding import gather_bitstreams
+    from ec504_imageencoder_amd.sharding import StepPipeline, shared_host_buffer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +248,7 @@ def main():
     enc = Mpeg1Encoder(W, H, qf, "full", max_frames=n, device=gpu_index)
     first = rank * n  # global frame index of this rank's first frame
     rgb = enc.synth(n, seed=seed, first_frame_index=first, device=dev)
-    # two output buffers: for N > 1 the gather of step k overlaps the encode of step k+1
+    # two output buffers: for N > 1 the exchange of step k overlaps the encode of step k+1
     outs = [torch.empty(enc.default_out_capacity(n), dtype=torch.uint8, device=dev) for _ in range(2)]
     if not distributed and args.pipeline:
         # one GPU: the library overlaps each batch's layout + gather (internal stream) with the next batch's
@@ -198,48 +257,55 @@ def main():
     metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in outs]
     sizes = torch.empty(n, dtype=torch.int64, device=dev)
     out, meta = outs[0], metas[0]
-    gathered = None
-    comm_stream = torch.cuda.Stream(device=dev) if distributed else None
-    encoded = [torch.cuda.Event() for _ in outs]      # encode into buffer b finished
-    drained = [None for _ in outs]                     # gather out of buffer b finished
-    pending = []                                       # buffers encoded but not yet gathered
     step_no = 0
 
-    def gather_one(b):
-        """The path's one exchange, on the side stream: per-rank byte counts, then the blobs to rank 0 over xGMI."""
-        nonlocal gathered
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(encoded[b])
-            total = int(metas[b][0].item())
-            res, _ = gather_bitstreams(outs[b][:total].cpu() if rehearsal else outs[b], total, dst=gathered)
+    pipe = None
+    if distributed:
+        # One encode to learn the size of a step's output, so that the gather buffers need not be worst-case sized
+        # (every step of the benchmark encodes the same frames; a real caller sizes them from frame_bound).
+        enc.encode(rgb, first, out=outs[0], sizes=sizes, meta=metas[0])
+        torch.cuda.synchronize(dev)
+        mine = torch.tensor([int(metas[0][0].item())], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        per_rank = (int(mine.item()) * 5 // 4 + 4095) & ~4095
+        host_buf = shm_path = None
+        if args.gather == "host":
+            name = f"ec504_bench_{os.environ.get('MASTER_PORT', '0')}"
             if rank == 0:
-                gathered = res if gathered is None or gathered.numel() < res.numel() else gathered
-            ev = torch.cuda.Event()
-            ev.record(comm_stream)
-            drained[b] = ev
+                host_buf, shm_path = shared_host_buffer(world * per_rank, 0, name)
+            dist.barrier()
+            if rank != 0:
+                host_buf, shm_path = shared_host_buffer(world * per_rank, rank, name)
+
+        if rehearsal:   # gloo moves host tensors: the blobs are staged through pinned host memory on the side stream
+            h_outs = [torch.empty(per_rank, dtype=torch.uint8, pin_memory=True) for _ in outs]
+            h_metas = [torch.zeros(2, dtype=torch.int64, pin_memory=True) for _ in outs]
+
+            def encode(b):
+                enc.encode(rgb, first, out=outs[b], sizes=sizes, meta=metas[b])
+                h_metas[b].copy_(metas[b], non_blocking=True)
+                h_outs[b].copy_(outs[b][:per_rank], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            pipe = StepPipeline(encode, h_outs, h_metas, world, rank, transport=args.gather, host_buffer=host_buf,
+                                gather_capacity=world * per_rank)
+        else:
+            def encode(b):
+                enc.encode(rgb, first, out=outs[b], sizes=sizes, meta=metas[b])
+            pipe = StepPipeline(encode, outs, metas, world, rank, transport=args.gather, host_buffer=host_buf,
+                                gather_capacity=world * per_rank)
 
     def step():
         nonlocal step_no
+        if distributed:
+            pipe.step()
+            return
         b = step_no % len(outs)
         step_no += 1
-        if distributed and drained[b] is not None:
-            torch.cuda.current_stream().wait_event(drained[b])   # buffer b is free again
         enc.encode(rgb, first, out=outs[b], sizes=sizes, meta=metas[b])
-        if distributed:
-            encoded[b].record(torch.cuda.current_stream())
-            pending.append(b)
-            if len(pending) > 1:                                  # gather lags one step behind the encode
-                gather_one(pending.pop(0))
-
-    def drain():
-        while pending:
-            gather_one(pending.pop(0))
 
     def fence():
         if distributed:
-            drain()
-            torch.cuda.synchronize(dev)
-            dist.barrier()
+            pipe.fence()
         else:
             enc.flush()
         torch.cuda.synchronize(dev)
@@ -258,12 +324,17 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = enc.profile_read()
+    kernel_times = enc.profile_read_times(cap=max(args.steps, 1) + 8)
+    launches, kernel_ms = len(kernel_times), float(sum(kernel_times))
     enc.profile(False)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if rank == 0 and pipe.result() is not None:
+            # the gathered stream of the last step begins with rank 0's own records (checked outside the timed region)
+            own = int(pipe.last_counts[0])
+            assert bytes(pipe.result()[:64].cpu().numpy()) == bytes(outs[(pipe.step_no - 1) % 2][:64].cpu().numpy()) and own > 0
 
     total_bytes, status = (int(x) for x in meta.cpu())
     assert (status & 0xFFFFFFFF) == 0, f"device status {status:#x}"
@@ -274,6 +345,7 @@ def main():
         out_per_frame = total_bytes / n
         alg_bytes_frame = 3 * W * H + out_per_frame            # RGB read once + emitted bytes
         k_ms = kernel_ms / max(launches, 1)
+        pmc = _committed_pmc(W, H, n)
         achieved = alg_bytes_frame * n / (k_ms * 1e-3) / 1e9 if launches else 0.0
         line = {
             "metric": "1080p I-frames/s" if (W, H) == (1920, 1080) else f"{W}x{H} I-frames/s",
@@ -282,14 +354,23 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_settle_ms": args.settle_ms,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32 (FDCT/VLC) + f64 (colour)", "data": "synthetic",
+            "dtype": "f32 (colour fast path, FDCT: exact integers in floats) + f64 (colour ties) + int32 (VLC, packing)",
+            "data": "synthetic",
             "config": {"workload": f"{n} x {W}x{H} synthetic RGB frames per GPU, FULL region (all macroblocks), quality_factor {qf}, "
                                    "input and output resident in HBM" + ("" if distributed or not args.pipeline else "; batch k's gather overlaps batch k+1's encode (two output buffers)"), "frames_per_gpu": n,
                        "global_frames": n * world, "bytes_out_per_frame": round(out_per_frame, 1),
-                       "parallelism": f"frames sharded {n}/GPU" + (", RCCL gather of bitstreams to rank 0" if distributed else "")},
+                       "parallelism": f"frames sharded {n}/GPU" + (
+                           (", grouped send/recv of the bitstreams to rank 0 (RCCL)" if args.gather == "xgmi" else
+                            ", every rank copies its bitstream into its slice of one pinned host buffer") if distributed else "")},
+            # "hbm" is the roofline BASELINE.json prices the path against; the resource that binds the kernel today is
+            # vector-ALU issue: see "valu" (and DESIGN.md, "Where the time goes")
             "roofline": {"bound": "hbm", "kernel": "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(W, H, n),
-                         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_frame * n)},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(pmc),
+                         "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
+                         "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,
+                         "kernel_ms_max": round(max(kernel_times), 4) if kernel_times else None, "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "valu-issue",
+                         "valu": valu_roofline(pmc, k_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
             head = out[:min(out.numel(), 4 * (W * H // 2))].cpu().numpy().tobytes()   # first frame records of rank 0
@@ -314,6 +395,8 @@ def main():
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
+        if args.gather == "host" and rank == 0 and shm_path:
+            os.unlink(shm_path)
         dist.destroy_process_group()
 
 

@@ -22,7 +22,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_encode_planes_host",
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
-    "m1v_profile_enable", "m1v_profile_read", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
+    "m1v_profile_enable", "m1v_profile_read", "m1v_profile_read_times", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
     "m1v_debug_set_input_mode",
 ]
 
@@ -92,6 +92,10 @@ def lib():
     L.m1v_profile_enable.restype = C.c_int
     L.m1v_profile_read.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.m1v_profile_read.restype = C.c_int
+    L.m1v_profile_read_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    L.m1v_profile_read_times.restype = C.c_int
+    L.m1v_debug_set_input_mode.argtypes = [vp, C.c_int]
+    L.m1v_debug_set_input_mode.restype = C.c_int
     L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
     L.m1v_debug_set_lds_words.restype = C.c_int
     L.m1v_debug_set_dense_threads.argtypes = [vp, C.c_int]

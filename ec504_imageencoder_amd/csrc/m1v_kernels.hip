@@ -1865,6 +1865,22 @@ int m1v_profile_read(m1v_encoder *e, int *launches, double *total_ms) {
     return M1V_OK;
 }
 
+int m1v_profile_read_times(m1v_encoder *e, float *ms, int cap, int *launches) {
+    if (!e || (cap > 0 && !ms)) return fail(M1V_E_ARG, "bad argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    int n = 0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(e->ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, e->ev[i], e->ev[i + 1]));
+        if (n < cap) ms[n] = t;
+        n++;
+    }
+    e->ev_used = 0;
+    if (launches) *launches = n;
+    return M1V_OK;
+}
+
 static int profile_event(m1v_encoder *e, hipStream_t st) {
     if (e->ev_used == e->ev.size()) {
         hipEvent_t ev;

@@ -197,6 +197,20 @@ class Mpeg1Encoder:
             raise EncoderError(rc, "m1v_profile_read")
         return n.value, ms.value
 
+    def profile_read_times(self, cap=4096):
+        """Durations (ms) of the dominant kernel's launches since profile(True), in launch order."""
+        buf, n = (C.c_float * cap)(), C.c_int(0)
+        rc = _ffi.lib().m1v_profile_read_times(self._h, buf, cap, C.byref(n))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_profile_read_times")
+        return [float(buf[i]) for i in range(min(n.value, cap))]
+
+    def debug_set_input_mode(self, mode):
+        """Test hook: -1 automatic, 0 byte loads, 2 funnel-shifted 28-byte loads (see mpeg1_hip.h)."""
+        rc = _ffi.lib().m1v_debug_set_input_mode(self._h, int(mode))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_debug_set_input_mode")
+
     def debug_set_lds_words(self, words):
         _ffi.lib().m1v_debug_set_lds_words(self._h, int(words))
 

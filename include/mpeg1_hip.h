@@ -147,10 +147,12 @@ int m1v_synth_device(uint8_t *d_rgb, size_t bytes_per_frame, int n_frames, uint6
                      uint64_t first_frame_index, void *stream);
 
 /* Kernel timing by HIP events recorded on the launch stream around the dominant kernel
- * (encode_strips).  enable!=0 starts collecting; m1v_profile_read synchronises the recorded events
+ * (k_encode_dense / k_encode_strips).  enable!=0 starts collecting; m1v_profile_read synchronises the recorded events
  * and returns launches/total milliseconds since the last read. */
 int m1v_profile_enable(m1v_encoder *enc, int enable);
 int m1v_profile_read(m1v_encoder *enc, int *launches, double *total_ms);
+/* The same, one duration per launch: ms[0 .. min(cap, *launches)) in launch order (for min / median / spread). */
+int m1v_profile_read_times(m1v_encoder *enc, float *ms, int cap, int *launches);
 
 /* Test hook: capacity in 32-bit words of the per-strip LDS bit buffer (0 = default).  A tiny value
  * forces the global-memory fallback path so that tests can cover it. */

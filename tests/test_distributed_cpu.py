@@ -65,3 +65,60 @@ def test_shard_range_partitions_exactly():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f1 == f0 + c0
+
+
+def _pipeline_worker(rank, world, port, n_per_rank, W, H, steps, transport, result_path):
+    """bench.py's own N > 1 step loop (StepPipeline: step / pending / drain / fence, two output buffers, the exchange
+    one step behind the encode) with the oracle as the per-rank producer.  Every step encodes DIFFERENT frames, so a
+    buffer handed on too early or too late shows up as wrong bytes."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import oracle_ffi as orc
+    from ec504_imageencoder_amd.sharding import StepPipeline, shared_host_buffer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cap = 64 * 1024 * n_per_rank
+    outs = [torch.zeros(cap, dtype=torch.uint8) for _ in range(2)]
+    metas = [torch.zeros(2, dtype=torch.int64) for _ in range(2)]
+    state = {"step": 0}
+
+    def encode(b):
+        first = (state["step"] * world + rank) * n_per_rank      # global frame index of this rank's batch in this step
+        frames = orc.synth_frames(n_per_rank, W, H, seed=504, first_index=first)
+        body, _ = orc.encode_frames(frames, n_per_rank, W, H, first, 12, orc.MODE_FULL)
+        outs[b][:len(body)] = torch.frombuffer(bytearray(body), dtype=torch.uint8)
+        outs[b][len(body):len(body) + 16] = 0xEE                  # garbage behind the payload must not travel
+        metas[b][0], metas[b][1] = len(body), 0
+        state["step"] += 1
+
+    host, path = (None, None)
+    if transport == "host":
+        if rank == 0:
+            host, path = shared_host_buffer(world * cap, 0, f"ec504_test_{port}", pin=False)
+        dist.barrier()
+        if rank != 0:
+            host, path = shared_host_buffer(world * cap, rank, f"ec504_test_{port}", pin=False)
+    pipe = StepPipeline(encode, outs, metas, world, rank, transport=transport, host_buffer=host)
+    for _ in range(steps):
+        pipe.step()
+    pipe.fence()
+    assert pipe.exchanges == steps and not pipe.pending
+    if rank == 0:
+        np.save(result_path, pipe.result().numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+    if path and rank == 0:
+        os.unlink(path)
+
+
+@pytest.mark.parametrize("world,transport", [(2, "xgmi"), (2, "host"), (3, "xgmi")])
+def test_step_pipeline_of_the_bench(orc, tmp_path, world, transport):
+    W, H, n_per_rank, steps = 176, 144, 2, 5
+    result = str(tmp_path / "last.npy")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), n_per_rank, W, H, steps, transport, result), nprocs=world, join=True)
+    got = np.load(result).tobytes()
+    first = (steps - 1) * world * n_per_rank                     # the last step's frames, all ranks, in rank order
+    frames = orc.synth_frames(world * n_per_rank, W, H, seed=504, first_index=first)
+    want, _ = orc.encode_frames(frames, world * n_per_rank, W, H, first, 12, orc.MODE_FULL)
+    assert got == want

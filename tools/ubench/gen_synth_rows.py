@@ -30,6 +30,7 @@ class S:
     def cvtf(s): d = s.r(); s.add(f"v_cvt_f32_i32 {d}, {d}")
     def max3(s): d = s.r(); s.add(f"v_max3_f32 {d}, {d}, %12, %13")
     def max3u(s): d = s.r(); s.add(f"v_max3_u32 {d}, {d}, %12, %13")
+    def pkfma(s): d = s.r(); s.i += 1; s.add(f"v_pk_fma_f32 %{14 + (s.i // 2) % 2}, %{14 + (s.i // 2) % 2}, %16, %17")
     def text(s): return "\\n".join(s.l) + "\\n"
 
 def colour_int(s, unpack):  # round-1 form: value = bits >> 15, flag = (bits & 0x7fff) >= limit, per pixel
@@ -42,6 +43,29 @@ def colour_flt(s, unpack):  # float form: trunc by and, fraction by sub, max3 ov
     for px in range(8):
         for c in range(3):
             (s.cvt() if unpack == "cvt" else s.andb())
+        for c in range(3): s.fma()
+        s.andb(); s.subf()
+        if px % 2: s.max3()
+    s.cmp()
+def colour_flt_pk(s):  # float form, FMAs packed two pixels at a time
+    for px in range(0, 8, 2):
+        for c in range(6): s.cvt()
+        for c in range(3): s.pkfma()
+        s.andb(); s.subf(); s.andb(); s.subf(); s.max3()
+    s.cmp()
+def colour_flt_half(s):  # float form, bytes 0 and 3 of each dword by and / shift (denormal operands), bytes 1, 2 by cvt
+    for px in range(8):
+        for c in range(3):
+            (s.cvt() if (px * 3 + c) % 4 in (1, 2) else s.andb())
+        for c in range(3): s.fma()
+        s.andb(); s.subf()
+        if px % 2: s.max3()
+    s.cmp()
+def colour_flt_den15(s):  # float form, every byte by shift/and at ONE scale: 6 integer ops per dword of 4 bytes
+    for px in range(8):
+        for c in range(3): s.andb()
+        if px % 2 == 0:
+            for c in range(3): s.lshr()   # 24 bytes = 6 dwords -> 12 extra shifts per row, 3 every other pixel
         for c in range(3): s.fma()
         s.andb(); s.subf()
         if px % 2: s.max3()
@@ -89,6 +113,9 @@ def build(name, fns):
     variants[name] = s
 build("int_cvt", [lambda s: colour_int(s, "cvt"), row_int, col_int, quant_int])
 build("flt_cvt", [lambda s: colour_flt(s, "cvt"), row_flt, col_flt, quant_flt])
+build("flt_pk", [colour_flt_pk, row_flt, col_flt, quant_flt])
+build("flt_half", [colour_flt_half, row_flt, col_flt, quant_flt])
+build("flt_den15", [colour_flt_den15, row_flt, col_flt, quant_flt])
 build("int_den", [lambda s: colour_int(s, "and"), row_int, col_int, quant_int])
 build("flt_den", [lambda s: colour_flt(s, "and"), row_flt, col_flt, quant_flt])
 # the same instructions, shuffled within the whole row-step (what perfect mixing would give)
@@ -98,11 +125,11 @@ for nm in ("int_cvt", "flt_cvt"):
 out = ['// GENERATED by gen_synth_rows.py - synthetic per-row instruction streams, see that file.',
        '#include <hip/hip_runtime.h>', '#include <stdio.h>',
        'template <int P> __global__ __launch_bounds__(256) void k(int iters, unsigned *out) {',
-       '    unsigned v[12]; for (int i = 0; i < 12; i++) v[i] = threadIdx.x + i; unsigned c0 = 12345, c1 = 77;']
+       '    unsigned v[12]; for (int i = 0; i < 12; i++) v[i] = threadIdx.x + i; unsigned c0 = 12345, c1 = 77; unsigned long long w0 = threadIdx.x, w1 = 3, w2 = 0x3f8000003f800000ull, w3 = 5;']
 names = list(variants)
 for i, nm in enumerate(names):
     out.append(f'    if (P == {i}) for (int it = 0; it < iters; it++) asm volatile("{variants[nm].text()}" : ' +
-               ", ".join(f'"+v"(v[{j}])' for j in range(12)) + ' : "v"(c0), "v"(c1) : "vcc");')
+               ", ".join(f'"+v"(v[{j}])' for j in range(12)) + ' : "v"(c0), "v"(c1), "v"(w0), "v"(w1), "v"(w2), "v"(w3) : "vcc");')
 out += ['    unsigned x = 0; for (int i = 0; i < 12; i++) x ^= v[i]; out[blockIdx.x * 256 + threadIdx.x] = x;', '}',
         'template <int P> void run(const char *name, int n, int waves, unsigned *d) {',
         '    const int iters = 2000, blocks = 256 * waves;', '    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);',
@@ -112,7 +139,7 @@ out += ['    unsigned x = 0; for (int i = 0; i < 12; i++) x ^= v[i]; out[blockId
         '    double ns = ms * 1e6 / ((double)waves * iters);',
         '    printf("%-20s %d waves/SIMD  %4d instr/row-step  %8.1f ns per row-step per wave per SIMD = %7.1f cycles @2.0GHz = %5.2f per instr\\n", name, waves, n, ns, ns * 2.0, ns * 2.0 / n);',
         '}', 'int main() {', '    unsigned *d; (void)hipMalloc(&d, 256 * 1024 * 8 * 4);', '    run<0>("warm", 1, 4, d);']
-for w in (4, 5):
+for w in (5,):
     for i, nm in enumerate(names):
         out.append(f'    run<{i}>("{nm}", {len(variants[nm].l)}, {w}, d);')
 out += ['    return 0;', '}']
