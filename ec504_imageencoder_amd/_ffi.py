@@ -10,8 +10,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libencoder.so")
 
 MODE_STRICT, MODE_FULL = 0, 1
-OK, E_ARG, E_UNENCODABLE, E_NOSPACE, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4, -5
-STATUS_UNENCODABLE, STATUS_NOSPACE = 1, 2
+OK, E_ARG, E_UNENCODABLE, E_NOSPACE, E_HIP, E_NODEVICE, E_SCRATCH = 0, -1, -2, -3, -4, -5, -6
+STATUS_UNENCODABLE, STATUS_NOSPACE, STATUS_SCRATCH = 1, 2, 4
 
 _u8p = C.POINTER(C.c_uint8)
 
@@ -23,7 +23,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_profile_read_times", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
-    "m1v_debug_set_input_mode",
+    "m1v_debug_set_input_mode", "m1v_reserve_scratch", "m1v_scratch_bytes",
 ]
 
 
@@ -96,6 +96,10 @@ def lib():
     L.m1v_profile_read_times.restype = C.c_int
     L.m1v_debug_set_input_mode.argtypes = [vp, C.c_int]
     L.m1v_debug_set_input_mode.restype = C.c_int
+    L.m1v_reserve_scratch.argtypes = [vp, C.c_int]
+    L.m1v_reserve_scratch.restype = C.c_int
+    L.m1v_scratch_bytes.argtypes = [vp]
+    L.m1v_scratch_bytes.restype = C.c_size_t
     L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
     L.m1v_debug_set_lds_words.restype = C.c_int
     L.m1v_debug_set_dense_threads.argtypes = [vp, C.c_int]

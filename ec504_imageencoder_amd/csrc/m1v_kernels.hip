@@ -893,15 +893,20 @@ struct DenseArgs {
     Geometry g;
     const uint8_t *rgb;
     const Tables *tab;
-    uint8_t *scratch;       // [frame][run][run_cap]
-    uint32_t *run_meta;     // [frame][run][4]: bits of segment 0, bits of segment 1, first word of segment 1
+    uint8_t *scratch;       // [frame][run][slot_bytes] compact slots (a run whose image fits the LDS image), then the overflow
+                            // arena: arena_slots x run_cap, handed out by an atomic counter to the runs that build in global memory
+    uint32_t *run_meta;     // [frame][run][4]: bits of segment 0, bits of segment 1, first word of segment 1, where the run's
+                            // bytes are (offset from `scratch` in 4-byte words)
+    uint32_t *arena_next;   // the counter (reset by k_frame_offsets of the same batch)
+    uint32_t slot_bytes, arena_slots;
+    unsigned long long arena_off; // byte offset of the arena inside scratch
     uint32_t *status;
     int n_frames;
     int threads;            // T
     int runs_per_frame;
     int lds_words;          // capacity of the LDS image of the run's bits
     int zero_iters;         // ceil(lds_words / T): rounds of T words that clear it
-    uint32_t run_cap;       // bytes per scratch slot
+    uint32_t run_cap;       // bytes of one arena slot: the worst case of a run
     unsigned long long *stamps;
 };
 
@@ -923,8 +928,8 @@ void k_encode_dense(DenseArgs a) {
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
-    uint32_t *slot32 = reinterpret_cast<uint32_t *>(
-        a.scratch + ((unsigned long long)frame * a.runs_per_frame + run) * a.run_cap);
+    const unsigned long long run_index = (unsigned long long)frame * a.runs_per_frame + run;
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + run_index * a.slot_bytes); // compact slot (common case)
 
     STAMP_INIT();
     const int bps = g.n_mbrows * 6;                 // blocks per strip
@@ -1027,42 +1032,65 @@ void k_encode_dense(DenseArgs a) {
     const uint32_t end_words = has_b ? base1 + ((bits1 + 31) >> 5) : ((bits0 + 31) >> 5);
     const uint32_t off = in_b ? base1 * 32u + 38u + (P - PA) : origin0 + P;
 
-    // ---- image too large for LDS: build it in the (zeroed) scratch slot with global atomics ----
-    const bool global_mode = end_words + 2 > (uint32_t)a.lds_words;
-    if (global_mode) {
-        uint32_t cap_words = a.run_cap >> 2;
-        for (uint32_t i = tid; i < cap_words; i += T) slot32[i] = 0;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        uint32_t *img = global_mode ? slot32 : image;
+    auto slice_headers = [&](uint32_t *img, bool swapped) {
         if (pos0 == 0) {
             uint32_t h0 = slice_word0(s0), h1 = kSliceWord1;
-            atomicOr(&img[0], global_mode ? __builtin_bswap32(h0) : h0);
-            atomicOr(&img[1], global_mode ? __builtin_bswap32(h1) : h1);
+            atomicOr(&img[0], swapped ? __builtin_bswap32(h0) : h0);
+            atomicOr(&img[1], swapped ? __builtin_bswap32(h1) : h1);
         }
         if (has_b) {
             uint32_t h0 = slice_word0(s0 + 1), h1 = kSliceWord1;
-            atomicOr(&img[base1], global_mode ? __builtin_bswap32(h0) : h0);
-            atomicOr(&img[base1 + 1], global_mode ? __builtin_bswap32(h1) : h1);
+            atomicOr(&img[base1], swapped ? __builtin_bswap32(h0) : h0);
+            atomicOr(&img[base1 + 1], swapped ? __builtin_bswap32(h1) : h1);
         }
-        uint32_t *m = a.run_meta + ((unsigned long long)frame * a.runs_per_frame + run) * 4;
-        m[0] = bits0;
-        m[1] = bits1;
-        m[2] = base1;
+    };
+    auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
+    uint32_t *meta = a.run_meta + run_index * 4;
+
+    // ---- image too large for LDS (rare): build it with global atomics in a zeroed, worst-case sized slot taken from
+    //      the overflow arena.  A branch of its own that ends the kernel, so that the common path below keeps its
+    //      uniform slot pointer (merging the two pointers into one variable measured 3 % slower on the common path).
+    if (end_words + 2 > (uint32_t)a.lds_words) {
+        if (tid == 0) wave_sums[17] = atomicAdd(a.arena_next, 1u);
+        __syncthreads();
+        const uint32_t got = wave_sums[17];
+        if (got >= a.arena_slots) { // arena exhausted: the caller re-encodes after m1v_reserve_scratch (M1V_E_SCRATCH)
+            if (tid == 0) {
+                atomicOr(a.status, (uint32_t)M1V_STATUS_SCRATCH);
+                meta[0] = meta[1] = 0;
+                meta[2] = meta[3] = 0;
+            }
+            return;
+        }
+        const unsigned long long where = a.arena_off + (unsigned long long)got * a.run_cap;
+        uint32_t *big = reinterpret_cast<uint32_t *>(a.scratch + where);
+        for (uint32_t i = tid; i < (a.run_cap >> 2); i += T) big[i] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            slice_headers(big, true);
+            meta[0] = bits0;
+            meta[1] = bits1;
+            meta[2] = base1;
+            meta[3] = (uint32_t)(where >> 2);
+        }
+        if (valid) put_block<true>(big, off, bb, walk);
+        if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+        return;
     }
-    if (valid) {
-        auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
-        if (global_mode)
-            put_block<true>(slot32, off, bb, walk);
-        else
-            put_block<false>(image, off, bb, walk);
+
+    // ---- common path: OR the bits into the LDS image, store it once to the run's compact slot ----
+    if (tid == 0) {
+        slice_headers(image, false);
+        meta[0] = bits0;
+        meta[1] = bits1;
+        meta[2] = base1;
+        meta[3] = (uint32_t)((run_index * a.slot_bytes) >> 2);
     }
+    if (valid) put_block<false>(image, off, bb, walk);
     STAMP(6);
     __syncthreads();
     STAMP(7);
-    if (!global_mode)
-        for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
+    for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
     STAMP(8);
 }
@@ -1079,6 +1107,7 @@ struct LayoutArgs {
     unsigned long long *out_total;       // may be null
     uint32_t *enc_status;                // status bits of the encode kernel; handed on and cleared by k_frame_offsets
     uint32_t *out_status;                // the caller's status word (or a private sink): the gather ORs into it
+    uint32_t *arena_next;                // overflow-arena counter of the dense encode kernel, reset here for the next batch
     int n_frames, n_strips;
 };
 
@@ -1137,6 +1166,7 @@ __global__ __launch_bounds__(1024) void k_frame_offsets(LayoutArgs a) {
         // gather has not started; the word is zero again for the next batch that uses this set of buffers
         *a.out_status = *a.enc_status;
         *a.enc_status = 0;
+        *a.arena_next = 0;
     }
 }
 
@@ -1182,19 +1212,18 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
 // ---- dense path: strips are concatenations of run segments ----------------------------------------
 struct DenseGeom {
     int n_frames, n_strips, bps, T, runs_per_frame;
-    uint32_t run_cap;
 };
 
 // Segment of strip s contributed by run w: which of the run's two segments, its bit count, its bytes.
 __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint32_t *meta_frame, int w, int s,
-                                                  uint32_t &byte_off_in_slot) {
+                                                  uint32_t &word_off) {
     int s0w = (w * d.T) / d.bps;
     const uint32_t *m = meta_frame + (size_t)w * 4;
     if (s0w == s) {
-        byte_off_in_slot = 0;
+        word_off = m[3];
         return m[0];
     }
-    byte_off_in_slot = m[2] * 4u;
+    word_off = m[3] + m[2];
     return m[1];
 }
 
@@ -1203,7 +1232,7 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
 constexpr int kMaxSeg = 6;
 struct StripDesc {
     uint32_t n;                 // number of segments, or ~0u: more than kMaxSeg (tiny run lengths) -> generic walk
-    uint32_t src_off[kMaxSeg];  // byte offset of the segment inside the frame's scratch area
+    uint32_t src_off[kMaxSeg];  // where the segment starts: offset from the scratch base in 4-byte words
     uint32_t bits[kMaxSeg];
     uint32_t pad[3];
 };
@@ -1234,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, const u
 #pragma unroll
                 for (int kk = 0; kk < kMaxSeg; kk++)
                     if (kk == k) {
-                        sd.src_off[kk] = (uint32_t)w * d.run_cap + boff;
+                        sd.src_off[kk] = boff;
                         sd.bits[kk] = L;
                     }
                 bits += L;
@@ -1290,7 +1319,6 @@ __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
         return;
     }
     size_t idx = (size_t)f * d.n_strips + s;
-    const uint8_t *slots = a.scratch + (size_t)f * d.runs_per_frame * d.run_cap;
     uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
     uint32_t n = a.strip_bytes[idx];
     const uint32_t nwords = (n + 3) >> 2;
@@ -1301,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
 #pragma unroll
             for (int k = 0; k < kMaxSeg; k++)
                 if ((uint32_t)k < sd.n) {
-                    val |= strip_bits_from(slots + sd.src_off[k], D, sd.bits[k], lo_bit);
+                    val |= strip_bits_from(a.scratch + (size_t)sd.src_off[k] * 4, D, sd.bits[k], lo_bit);
                     D += sd.bits[k];
                 }
         } else { // many short runs per strip: walk the run metadata
@@ -1309,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
             int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
             for (int w = w_lo; w <= w_hi; w++) {
                 uint32_t boff, L = dense_segment(d, mf, w, s, boff);
-                val |= strip_bits_from(slots + (size_t)w * d.run_cap + boff, D, L, lo_bit);
+                val |= strip_bits_from(a.scratch + (size_t)boff * 4, D, L, lo_bit);
                 D += L;
             }
         }
@@ -1530,7 +1558,12 @@ struct m1v_encoder {
     bool dense;        // blocks per strip >= 64: k_encode_dense, else one workgroup per strip
     bool narrow;       // no AC level can reach +-128: one byte per staged level
     int dense_T, runs_per_frame;
-    uint32_t run_cap;
+    uint32_t run_cap;       // worst-case bytes of one run = one slot of the overflow arena
+    uint32_t slot_bytes;    // compact slot of a run (what the LDS image can hold)
+    uint32_t arena_slots;
+    size_t arena_off;
+    int image_words;        // capacity of the dense kernel's LDS image in effect
+    bool reserve_worst;     // overflow arena sized for every run (m1v_reserve_scratch, or a forced tiny LDS image)
     size_t scratch_bytes;   // per batch state
     bool pipelined;         // layout + gather of batch k on `side` while batch k+1 encodes on the caller's stream
     unsigned calls;
@@ -1621,17 +1654,31 @@ static int configure_path(m1v_encoder *e, int dense_T) {
         e->dense_T = T;
         int nb = g.n_strips * bps;
         e->runs_per_frame = (nb + T - 1) / T;
-        // two word-aligned segments of at most T blocks of <= 886 + 2 bits, two slice headers, slack
+        // worst case of a run: two word-aligned segments of at most T blocks of <= 886 + 2 bits, two slice headers, slack
         e->run_cap = (uint32_t)(((((size_t)T * (kMaxBlockBits + 2) + 2 * 38 + 3 * 32 + 7) / 8) + 32 + 15) & ~(size_t)15);
-        need = (size_t)e->max_frames * e->runs_per_frame * e->run_cap;
-        meta = (size_t)e->max_frames * e->runs_per_frame * 4 * sizeof(uint32_t);
+        // LDS image of the run's bits: zeroing it costs time, outgrowing it the slow global-atomics path.  A run of 256
+        // blocks needs ~150 words at quality 12 on noise; scale the default with the quantiser (finer quantisers emit
+        // more bits per block).  The compact scratch slot of a run is exactly that image.
+        e->image_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 512 : (e->qf <= 50 ? 1024 : (e->qf <= 76 ? 2048 : 4096)));
+        // + 128: an odd number of 128-byte lines, so that the slots (of which only the first third is written at quality
+        // 12) do not all start on the same few memory channels (a power-of-two stride measured 3 % slower)
+        e->slot_bytes = (uint32_t)((((size_t)e->image_words * 4 + 127) & ~(size_t)127) | 128);
+        // Scratch: one compact slot per run + an overflow arena of worst-case slots for the runs whose image outgrows LDS
+        // (handed out by an atomic counter).  By default the arena holds 1/256 of the runs (quality 12 noise needs none);
+        // m1v_reserve_scratch(enc, 1) sizes it for all of them — what every run had in round 1, 47x the payload.
+        const size_t runs = (size_t)e->max_frames * e->runs_per_frame;
+        e->arena_slots = (uint32_t)(e->reserve_worst ? runs : (runs / 256 > 32 ? runs / 256 : (runs < 32 ? runs : 32)));
+        e->arena_off = runs * e->slot_bytes;
+        need = e->arena_off + (size_t)e->arena_slots * e->run_cap;
+        if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
+        meta = runs * 4 * sizeof(uint32_t);
     } else {
         need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
     }
     const int sets = e->pipelined ? 2 : 1;
     for (int i = 0; i < sets; i++) {
         m1v_encoder::Batch &bt = e->batch[i];
-        if (need > e->scratch_bytes || !bt.scratch) {
+        if (need != e->scratch_bytes || !bt.scratch) {
             (void)hipFree(bt.scratch);
             bt.scratch = nullptr;
             if (hipMalloc(&bt.scratch, need) != hipSuccess) return fail(M1V_E_HIP, "scratch allocation failed%s");
@@ -1648,14 +1695,14 @@ static int configure_path(m1v_encoder *e, int dense_T) {
             if (err == hipSuccess) err = hipMalloc(&bt.strip_desc, nslots * sizeof(StripDesc));
             if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
-            if (err == hipSuccess) err = hipMalloc(&bt.status, 2 * sizeof(uint32_t)); // [0] encode status, [1] sink
-            if (err == hipSuccess) err = hipMemset(bt.status, 0, 2 * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.status, 4 * sizeof(uint32_t)); // [0] encode status, [1] sink, [2] arena counter
+            if (err == hipSuccess) err = hipMemset(bt.status, 0, 4 * sizeof(uint32_t));
             if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
             if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.gather_done, hipEventDisableTiming);
             if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
         }
     }
-    if (need > e->scratch_bytes) e->scratch_bytes = need;
+    e->scratch_bytes = need;
     return M1V_OK;
 }
 
@@ -1696,6 +1743,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->dense = bps >= kWave;
     e->dense_T = 0;
     e->scratch_bytes = 0;
+    e->reserve_worst = false;
     e->pipelined = false;
     e->calls = 0;
     e->side = nullptr;
@@ -1790,8 +1838,22 @@ size_t m1v_frame_bound(const m1v_encoder *e) {
 int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
     e->lds_words = words > 0 ? (words < 4 ? 4 : words) : 0;
-    return M1V_OK;
+    if (!e->dense) return M1V_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return configure_path(e, e->dense_T); // (a small forced image sends many runs to the overflow arena: M1V_STATUS_SCRATCH)
 }
+
+int m1v_reserve_scratch(m1v_encoder *e, int worst_case) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    if (!e->dense) return M1V_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    e->reserve_worst = worst_case != 0;
+    return configure_path(e, e->dense_T);
+}
+
+size_t m1v_scratch_bytes(const m1v_encoder *e) { return e ? e->scratch_bytes * (e->pipelined ? 2 : 1) : 0; }
 
 int m1v_set_pipelined(m1v_encoder *e, int enable) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
@@ -1922,6 +1984,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.out_total = (unsigned long long *)d_total;
     l.enc_status = bt.status;
     l.out_status = d_status ? d_status : bt.status + 1;
+    l.arena_next = bt.status + 2;
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
 
@@ -1939,8 +2002,12 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         // LDS image of the run's bits: zeroing it is ~3 % of the kernel per KiB-word, outgrowing it costs the
         // slow global-atomics path.  A run of 256 blocks needs ~230 words at quality 12 on noise; scale the
         // default with the quantiser (finer quantisers emit more bits per block).
-        a.lds_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 1024 : (e->qf <= 50 ? 2048 : 4096));
+        a.lds_words = e->image_words;
         a.run_cap = e->run_cap;
+        a.slot_bytes = e->slot_bytes;
+        a.arena_slots = e->arena_slots;
+        a.arena_off = e->arena_off;
+        a.arena_next = bt.status + 2;
         a.stamps = e->d_stamps;
         const int stride = e->narrow ? kStageStride8 : kStageStride16;
         a.zero_iters = (a.lds_words + e->dense_T - 1) / e->dense_T;
@@ -1982,7 +2049,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.bps = g.n_mbrows * 6;
         d.T = e->dense_T;
         d.runs_per_frame = e->runs_per_frame;
-        d.run_cap = e->run_cap;
         hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.run_meta, bt.strip_bytes,
                            bt.strip_off, bt.strip_desc, bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
@@ -2122,14 +2188,22 @@ long m1v_encode_planes_host(m1v_encoder *e, const uint8_t *rgb, int n_frames, in
                                    hipMemcpyDeviceToHost, hp.work));
         }
     }
-    int r = m1v_encode_device(e, hp.d_in, n_frames, first_frame_index, hp.d_out, dcap, (uint64_t *)hp.d_meta,
-                              (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), hp.work);
-    if (r != M1V_OK) return drained(r);
-    if (m1v_flush(e, hp.work) != M1V_OK) return drained(M1V_E_HIP);
     std::vector<unsigned long long> meta((size_t)n_frames + 2);
-    HIP_TRY_DRAIN(hipMemcpyAsync(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost, hp.work));
-    HIP_TRY_DRAIN(hipStreamSynchronize(hp.work));
-    uint32_t status = (uint32_t)meta[(size_t)n_frames + 1];
+    uint32_t status = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int r = m1v_encode_device(e, hp.d_in, n_frames, first_frame_index, hp.d_out, dcap, (uint64_t *)hp.d_meta,
+                                  (uint64_t *)(hp.d_meta + n_frames), (uint32_t *)(hp.d_meta + n_frames + 1), hp.work);
+        if (r != M1V_OK) return drained(r);
+        if (m1v_flush(e, hp.work) != M1V_OK) return drained(M1V_E_HIP);
+        HIP_TRY_DRAIN(hipMemcpyAsync(meta.data(), hp.d_meta, meta.size() * 8, hipMemcpyDeviceToHost, hp.work));
+        HIP_TRY_DRAIN(hipStreamSynchronize(hp.work));
+        status = (uint32_t)meta[(size_t)n_frames + 1];
+        if (!(status & M1V_STATUS_SCRATCH) || attempt == 1) break;
+        // more runs outgrew their compact scratch slot than the overflow arena holds: reserve the worst case, encode again
+        int rr = m1v_reserve_scratch(e, 1);
+        if (rr != M1V_OK) return drained(rr);
+    }
+    if (status & M1V_STATUS_SCRATCH) return drained(fail(M1V_E_SCRATCH, "scratch exhausted%s"));
     unsigned long long total = meta[n_frames];
     if (status & M1V_STATUS_UNENCODABLE)
         return fail(M1V_E_UNENCODABLE, "an AC level has |level| >= 256 (the reference crashes here)%s");

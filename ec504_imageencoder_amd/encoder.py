@@ -112,8 +112,11 @@ class Mpeg1Encoder:
         status &= 0xFFFFFFFF
         if status & _ffi.STATUS_UNENCODABLE:
             raise EncoderError(_ffi.E_UNENCODABLE, "encode: |level| >= 256 (the reference crashes on this input)")
-        if status & _ffi.STATUS_NOSPACE:
-            out = torch.empty(self.frame_bound * rgb.shape[0], dtype=torch.uint8, device=rgb.device)
+        if status & (_ffi.STATUS_NOSPACE | _ffi.STATUS_SCRATCH):
+            if status & _ffi.STATUS_SCRATCH:        # more runs overflowed their compact slot than the arena holds
+                self.reserve_scratch(True)
+            if status & _ffi.STATUS_NOSPACE:
+                out = torch.empty(self.frame_bound * rgb.shape[0], dtype=torch.uint8, device=rgb.device)
             return self._retry_bytes(rgb, first_frame_index, out)
         return out[:total].cpu().numpy().tobytes(), [int(s) for s in sizes[:rgb.shape[0]].cpu()]
 
@@ -123,8 +126,18 @@ class Mpeg1Encoder:
         self.flush()
         torch.cuda.synchronize(rgb.device)
         total, status = (int(x) for x in meta.cpu())
-        if status & 0xFFFFFFFF:
-            raise EncoderError(_ffi.E_NOSPACE, "encode")
+        status &= 0xFFFFFFFF
+        if status & _ffi.STATUS_NOSPACE:            # scratch was the first obstacle, the output buffer is the second
+            out = torch.empty(self.frame_bound * rgb.shape[0], dtype=torch.uint8, device=rgb.device)
+            out, sizes, meta = self.encode(rgb, first_frame_index, out=out)
+            self.flush()
+            torch.cuda.synchronize(rgb.device)
+            total, status = (int(x) for x in meta.cpu())
+            status &= 0xFFFFFFFF
+        if status & _ffi.STATUS_UNENCODABLE:
+            raise EncoderError(_ffi.E_UNENCODABLE, "encode: |level| >= 256 (the reference crashes on this input)")
+        if status:
+            raise EncoderError(_ffi.E_NOSPACE if status & _ffi.STATUS_NOSPACE else _ffi.E_SCRATCH, "encode")
         return out[:total].cpu().numpy().tobytes(), [int(s) for s in sizes[:rgb.shape[0]].cpu()]
 
     def encode_host(self, rgb_np, first_frame_index=0, with_planes=False):
@@ -204,6 +217,15 @@ class Mpeg1Encoder:
         if rc != _ffi.OK:
             raise EncoderError(rc, "m1v_profile_read_times")
         return [float(buf[i]) for i in range(min(n.value, cap))]
+
+    def reserve_scratch(self, worst_case=True):
+        """Size the overflow arena for every run (True) or return to the default 1/256 (False); see mpeg1_hip.h."""
+        rc = _ffi.lib().m1v_reserve_scratch(self._h, 1 if worst_case else 0)
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_reserve_scratch")
+
+    def scratch_bytes(self):
+        return int(_ffi.lib().m1v_scratch_bytes(self._h))
 
     def debug_set_input_mode(self, mode):
         """Test hook: -1 automatic, 0 byte loads, 2 funnel-shifted 28-byte loads (see mpeg1_hip.h)."""

@@ -58,11 +58,13 @@ enum {
                                -> segfault); output of the batch is undefined                       */
     M1V_E_NOSPACE = -3,     /* output buffer too small                                             */
     M1V_E_HIP = -4,         /* HIP runtime error, see m1v_last_error()                             */
-    M1V_E_NODEVICE = -5     /* no usable gfx950 device                                             */
+    M1V_E_NODEVICE = -5,    /* no usable gfx950 device                                             */
+    M1V_E_SCRATCH = -6      /* the batch needs more scratch than reserved: m1v_reserve_scratch(enc, 1)
+                               and encode again (the host-buffer entry points do so themselves)       */
 };
 
 /* bits of the device status word (m1v_encode_device's d_status) */
-enum { M1V_STATUS_UNENCODABLE = 1u, M1V_STATUS_NOSPACE = 2u };
+enum { M1V_STATUS_UNENCODABLE = 1u, M1V_STATUS_NOSPACE = 2u, M1V_STATUS_SCRATCH = 4u };
 
 typedef struct m1v_encoder m1v_encoder;
 
@@ -74,6 +76,15 @@ const char *m1v_last_error(void); /* thread-local, never NULL */
 int m1v_create(m1v_encoder **out, int device, int width, int height, int channels,
                int quality_factor, int mode, int max_frames);
 void m1v_destroy(m1v_encoder *enc);
+
+/* Scratch policy.  Every run of 256 blocks owns a compact slot (what the kernel's LDS image of its bits can hold: 2 KiB at
+ * quality <= 25); runs that emit more build their bits in a worst-case sized slot (28 KiB) taken from an overflow arena.  By
+ * default the arena holds 1/256 of the runs — about 4x the payload in total at quality 12, where round 1 reserved 47x.
+ * A batch that exhausts it reports M1V_STATUS_SCRATCH in its status word (its output is then undefined):
+ * m1v_reserve_scratch(enc, 1) sizes the arena for every run (no batch can exhaust that), 0 returns to the default.
+ * Both reallocate: call them between batches. */
+int m1v_reserve_scratch(m1v_encoder *enc, int worst_case);
+size_t m1v_scratch_bytes(const m1v_encoder *enc); /* device bytes currently held as scratch */
 
 /* geometry helpers */
 int m1v_strips(const m1v_encoder *enc);          /* x_extent / 16 */
@@ -92,7 +103,7 @@ size_t m1v_file_prolog(uint8_t out[27]);
  * never leaves the buffer's last word.
  *   d_frame_sizes  uint64[n_frames] bytes of each record (may be NULL)
  *   d_total        uint64[1] total bytes written (may be NULL)
- *   d_status       uint32[1] OR of M1V_STATUS_* (may be NULL) */
+ *   d_status       uint32[1] OR of M1V_STATUS_* (may be NULL; M1V_STATUS_SCRATCH: see m1v_reserve_scratch) */
 int m1v_encode_device(m1v_encoder *enc, const uint8_t *d_rgb, int n_frames, int first_frame_index,
                       uint8_t *d_out, size_t out_cap, uint64_t *d_frame_sizes, uint64_t *d_total,
                       uint32_t *d_status, void *stream);

@@ -510,3 +510,43 @@ def test_fuzz_slice(torch_cuda, orc):
     cases, skipped, fails = fuzz_parity.run(budget=60.0, seed=20261004, max_cases=160, max_pixels=1024 * 800, verbose=False)
     assert not fails, fails[:5]
     assert cases >= 40 and skipped < cases // 2
+
+
+def test_scratch_is_compact_and_overflow_is_handled(torch_cuda, orc):
+    """Round 1 reserved a worst-case slot (28 KiB) per run of 256 blocks: 1.6 GB for 34 MB of payload.  Now a run owns a
+    compact slot and only runs that outgrow the LDS image take a worst-case slot from an overflow arena:
+    (1) 300 x 1080p at quality 12 holds less than 4x its payload as scratch and the noise benchmark never overflows;
+    (2) when every run overflows (forced here with a tiny LDS image; heavy pictures stay below the default compact slot at
+        every quality factor tried) the default arena is exhausted -> M1V_STATUS_SCRATCH, and after reserve_scratch() (what
+        encode_to_bytes does on its own) the stream equals the oracle's."""
+    torch = torch_cuda
+    from ec504_imageencoder_amd import _ffi
+    W, H, n = 1920, 1080, 300
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    rgb = enc.synth(n, seed=504)
+    out, sizes, meta = enc.encode(rgb, 0)
+    torch.cuda.synchronize()
+    total, status = (int(x) for x in meta.cpu())
+    assert status == 0
+    assert enc.scratch_bytes() < 4 * total, (enc.scratch_bytes(), total)
+    enc.close()
+
+    rng = np.random.default_rng(9)
+    W, H, n = 96, 1088, 8           # 6 strips x 68 macroblock rows = 2448 blocks: 10 runs per frame, 80 in the batch
+    pic = _heavy_picture(rng, W, H, 6, 700)                    # every block codes six isolated coefficients: > 64 bits
+    heavy = np.ascontiguousarray(np.broadcast_to(pic, (n, H, W, 3)))
+    want, wsizes = orc.encode_frames(heavy, n, W, H, 0, 12, orc.MODE_FULL)
+    enc = _enc(W, H, 12, "full", max_frames=n)
+    enc.debug_set_lds_words(64)     # 256-byte LDS image (a realistic picture does not outgrow the default 2 KiB): every run overflows
+    dev = torch.from_numpy(heavy).cuda()
+    out, sizes, meta = enc.encode(dev, 0)
+    torch.cuda.synchronize()
+    status = int(meta.cpu()[1]) & 0xFFFFFFFF
+    assert status & _ffi.STATUS_SCRATCH, status         # 80 runs overflow, the default arena holds 32
+    before = enc.scratch_bytes()
+    got, gsizes = enc.encode_to_bytes(dev, 0)           # reserves the worst case and encodes again
+    assert got == want and gsizes == [int(x) for x in wsizes]
+    assert enc.scratch_bytes() > before
+    got2, _ = enc.encode_to_bytes(dev, 0)               # and stays correct on the next batch (counter reset)
+    assert got2 == want
+    enc.close()

@@ -53,7 +53,8 @@ meta = torch.zeros(2, dtype=torch.int64, device="cuda")
 times = {nm: [] for nm in a.names}
 ref = None
 for r in range(a.rounds + 1):
-    for nm in a.names:
+    # alternate the order from round to round: within a round the later variants run on warmer clocks
+    for nm in (a.names if r % 2 == 0 else list(reversed(a.names))):
         L, h = libs[nm]
         L.m1v_profile_enable(h, 1)
         for _ in range(a.reps):
