@@ -392,6 +392,23 @@ def main():
                 res[kind] = round(3 * m / (time.perf_counter() - t0), 1)
             line["host_buffer_path"] = {"value": res["pinned"], "pageable": res["pageable"], "unit": "frames/s", "frames": m,
                                         "note": "m1v_encode_host: synchronous H2D + encode + D2H; pinned vs pageable input"}
+            # the side kernels of the path, device resident: the Y/Cb/Cr planes of the image_<k>.bit files (k_convert4:
+            # 3 B in + 3 B out per pixel) and the coefficient-only kernel of BASELINE config 2 (3 B in, 128 B out per block)
+            side = {}
+            for name, fn, bytes_per_frame in (("planes", lambda: enc.convert(rgb[:m]), 6 * W * H),
+                                              ("coefficients", lambda: enc.coefficients(rgb[:m]), 3 * W * H + enc.blocks_per_frame * 128)):
+                for _ in range(3):
+                    fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(5):
+                    fn()
+                b.record()
+                torch.cuda.synchronize(dev)
+                ms = a.elapsed_time(b) / 5
+                side[name] = {"ms": round(ms, 4), "frames": m, "achieved_gbs": round(bytes_per_frame * m / (ms * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(bytes_per_frame * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            line["side_kernels"] = side
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -1406,6 +1406,66 @@ __global__ __launch_bounds__(256) void k_convert(const uint8_t *rgb, int C, unsi
     }
 }
 
+// The same planes, four pixels per lane (frames whose pixel count is a multiple of 4, 4-byte aligned buffers): the 12 or
+// 16 input bytes arrive as dwords, every byte is converted once and feeds all three components, ONE fraction test covers the
+// group's twelve sums (the fp64 re-evaluation runs only behind it), and each plane gets one packed dword store.
+// HBM-bound: 3 or 4 bytes in, 3 bytes out per pixel.
+template <int C>
+__global__ __launch_bounds__(256) void k_convert4(const uint32_t *rgb, unsigned long long groups_frame, int n_frames,
+                                                  uint32_t *planes) {
+    const CompCoefF ky = comp_coef_f(0), kcb = comp_coef_f(1), kcr = comp_coef_f(2); // uniform: scalar registers
+    const unsigned long long total = groups_frame * (unsigned long long)n_frames;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long f = i / groups_frame, gidx = i - f * groups_frame;
+        uint32_t w[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) w[k] = rgb[i * C + k];
+        float lowest = 1.0f, t[3][4], p[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            auto chan = [&](int ch) -> uint32_t {
+                int byte = C * j + ch;
+                return (w[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+            };
+            const float r = (float)chan(0), g = (float)chan(1), b = (float)chan(2);
+            t[0][j] = fmaf(r, ky.kr, fmaf(g, ky.kg, fmaf(b, ky.kb, ky.k0)));
+            t[1][j] = fmaf(r, kcb.kr, fmaf(g, kcb.kg, fmaf(b, kcb.kb, kcb.k0)));
+            t[2][j] = fmaf(r, kcr.kr, fmaf(g, kcr.kg, fmaf(b, kcr.kb, kcr.k0)));
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                p[c][j] = clear_fraction(t[c][j]);
+                lowest = fminf(lowest, t[c][j] - p[c][j]);
+            }
+        }
+        if (lowest < kFracLow) { // rare: some sum of the group is a tie (or next to one) of the reference's formulas
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                auto chan = [&](int ch) -> int {
+                    int byte = C * j + ch;
+                    return (int)((w[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
+                };
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    if (t[c][j] - p[c][j] < kFracLow) {
+                        const CompCoef d = comp_coef(c);
+                        p[c][j] = m1vf::kPxBiasF + (float)component_fp64(chan(0), chan(1), chan(2), d.k0, d.kr, d.kg, d.kb);
+                    }
+            }
+        }
+        // p = 256 + value: the value is the top 8 mantissa bits
+        const unsigned long long plane_words = groups_frame;
+        uint32_t *o = planes + f * 3 * plane_words + gidx;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) packed |= ((__float_as_uint(p[c][j]) >> 15) & 0xffu) << (8 * j);
+            o[c * plane_words] = packed;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_subsample(const uint8_t *cb, const uint8_t *cr, int W, int H,
                                                    uint8_t *cbs, uint8_t *crs) {
     int sw = W / 2, sh = H / 2;
@@ -2248,6 +2308,18 @@ int m1v_convert_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, uint8
     HIP_TRY(hipSetDevice(e->device));
     unsigned long long npx = (unsigned long long)e->g.W * e->g.H;
     unsigned long long total = npx * n_frames;
+    if (npx % 4 == 0 && (((uintptr_t)d_rgb | (uintptr_t)d_planes) & 3) == 0) { // four pixels per lane, dword loads and stores
+        total /= 4;
+        unsigned blocks = (unsigned)((total + 255) / 256 > 131072 ? 131072 : (total + 255) / 256);
+        if (e->g.C == 3)
+            hipLaunchKernelGGL(k_convert4<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_rgb,
+                               npx / 4, n_frames, (uint32_t *)d_planes);
+        else
+            hipLaunchKernelGGL(k_convert4<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_rgb,
+                               npx / 4, n_frames, (uint32_t *)d_planes);
+        HIP_TRY(hipGetLastError());
+        return M1V_OK;
+    }
     unsigned blocks = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(k_convert, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_rgb, e->g.C, npx,
                        n_frames, d_planes);

@@ -550,3 +550,25 @@ def test_scratch_is_compact_and_overflow_is_handled(torch_cuda, orc):
     got2, _ = enc.encode_to_bytes(dev, 0)               # and stays correct on the next batch (counter reset)
     assert got2 == want
     enc.close()
+
+
+def test_plane_conversion_paths(torch_cuda, orc):
+    """m1v_convert_device has two kernels: four pixels per lane with dword loads and packed stores (pixel count a multiple
+    of 4, aligned pointers) and the byte-wise one.  Both, for 3 and 4 channels, against the oracle's planes — on noise and
+    on a grey picture (r = g = b: every chroma sample is an exact tie that takes the fp64 path)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    for (W, H, C) in ((64, 48, 3), (64, 48, 4), (37, 23, 3), (37, 23, 4)):
+        noise = rng.integers(0, 256, (1, H, W, C), dtype=np.uint8)
+        grey = np.repeat(rng.integers(0, 256, (1, H, W, 1), dtype=np.uint8), C, 3)
+        for pic in (noise, grey):
+            e = Mpeg1Encoder_for_planes(W, H, C)
+            got = e.convert(torch.from_numpy(pic).cuda()).cpu().numpy()[0]
+            Y, Cb, Cr = orc.convert(pic, channels=C)
+            assert np.array_equal(got[0], Y) and np.array_equal(got[1], Cb) and np.array_equal(got[2], Cr), (W, H, C)
+            e.close()
+
+
+def Mpeg1Encoder_for_planes(W, H, C):
+    from ec504_imageencoder_amd import Mpeg1Encoder
+    return Mpeg1Encoder(W, H, 12, "full", channels=C, max_frames=1)
