@@ -91,7 +91,9 @@ M1V_HD void fdct_row_f(const F p[8], F out[8]) {
     out[6] = floor_(t[3]); // x7 >> 10
     out[7] = floor_(t[4]); // (x2 - x5) >> 10
     out[1] = floor_(t[5]); // (x2 + x5) >> 10
-    // (x * 181) >> 17: the product needs 28 bits, so these two go through the integer multiplier
+    // (x * 181) >> 17: the product needs 28 bits, so these two go through the integer multiplier — the 32-bit one
+    // (v_mul_lo_u32): a v_mul_i32_i24 inside a stream of float instructions costs 20-45 cycles on gfx950
+    // (tools/ubench/stream_probe.hip, profiles/r02_stream_probe.txt), v_mul_lo_u32 about 5
     out[3] = F((float)(M1V_MUL24(to_int(t[6] * F(1024.0f)), 181) >> 17));
     out[5] = F((float)(M1V_MUL24(to_int(t[7] * F(1024.0f)), 181) >> 17));
 }

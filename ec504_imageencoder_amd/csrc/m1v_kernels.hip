@@ -43,7 +43,7 @@
 #include "../../include/mpeg1_hip.h"
 
 #define M1V_HD __host__ __device__ __forceinline__
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && defined(M1V_USE_MUL24) // A/B builds only: see fdct_f32.h on why not
 #define M1V_MUL24(a, b) __mul24((a), (b))
 #endif
 #include "fdct_f32.h"
@@ -244,7 +244,11 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         out[j + 1] = clear_fraction(t1);
         lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
     }
+#if M1V_EXP == 6 // timing experiment: no rare branch at all
+    if (false) {
+#else
     if (lowest < kFracLow) { // rare: redo the row's flagged pixels in the reference's arithmetic
+#endif
         // Written as a recomputation from the row's bytes (same instructions, same values); on the main path (aligned
         // 3-byte pixels) the compiler instead keeps the eight sums alive across the branch (measured 8 % faster than
         // recomputing: the branch is taken for half of the rows).  The input modes with more raw registers per row (4-byte
@@ -264,8 +268,12 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         for (int j = 0; j < 8; j++) {
             const uint32_t r = chan2(j, 0), gg = chan2(j, 1), b = chan2(j, 2);
             const float t = component_t(r, gg, b, k);
+#if M1V_EXP == 5 // timing experiment: the per-pixel test stays, the fp64 evaluation is replaced by one float op
+            if (t - clear_fraction(t) < kFracLow) out[j] = out[j] - 1.0f;
+#else
             if (t - clear_fraction(t) < kFracLow)
                 out[j] = m1vf::kPxBiasF + (float)component_fp64((int)r, (int)gg, (int)b, d.k0, d.kr, d.kg, d.kb);
+#endif
         }
     }
 }
@@ -925,8 +933,18 @@ void k_encode_dense(DenseArgs a) {
     uint32_t *stage = wave_sums + 32;              // T blocks x kStride words
     uint32_t *image = stage + kStride * T;         // a.lds_words
 
+#if defined(M1V_STAGGER) // experiment: start the first generation of workgroups at different phases
+    uint32_t stagger_zero = 0; // stays 0; a plain (non-volatile) asm so that the compiler's view of memory is unchanged
+    if (blockIdx.x < M1V_STAGGER_BLOCKS) {
+        const int ph = (int)((blockIdx.x * 2654435761u) >> 20) % M1V_STAGGER;
+        for (int i = 0; i < ph; i++) asm("s_sleep %1" : "+s"(stagger_zero) : "n"(M1V_STAGGER_SLEEP));
+    }
+#endif
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
+#if defined(M1V_STAGGER)
+    run += (int)stagger_zero;
+#endif
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
     const unsigned long long run_index = (unsigned long long)frame * a.runs_per_frame + run;
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + run_index * a.slot_bytes); // compact slot (common case)

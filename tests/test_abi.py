@@ -159,8 +159,9 @@ def test_hot_kernel_consumes_pixel_rows_as_they_arrive(built):
 
 def test_hot_kernel_shape_of_round_2(built):
     """Round-2 properties of the dense kernel, read off the disassembly so that a refactor cannot lose them silently:
-    the FDCT runs on the float pipe (the only 24-bit integer multiplies left are the sixteen (x * 181) >> 17 of the row
-    pass, and no v_mad_i32_i24), the quantised levels leave as 64 LDS byte stores, and the waves of a
+    the FDCT runs on the float pipe and no 24-bit integer multiply is left in the kernel (v_mul_i32_i24 / v_mad_i32_i24
+    cost 20-45 cycles each inside a float stream, profiles/r02_stream_probe.txt; the sixteen (x * 181) >> 17 of the row
+    pass use the 32-bit multiplier), the quantised levels leave as 64 LDS byte stores, and the waves of a
     workgroup meet only twice on the common path (scan, store) plus twice on the global-memory fallback (arena slot, clear)."""
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     obj = os.path.join(ROOT, "ec504_imageencoder_amd", "csrc", "m1v_kernels.o")
@@ -180,7 +181,7 @@ def test_hot_kernel_shape_of_round_2(built):
     assert m
     ops = [l.split()[0] for l in m.group(1).splitlines() if l.strip() and not l.strip().startswith(("/", ";"))]
     count = lambda name: sum(1 for o in ops if o.startswith(name))
-    assert count("v_mad_i32_i24") == 0 and count("v_mul_i32_i24") == 16, (count("v_mad_i32_i24"), count("v_mul_i32_i24"))
+    assert count("v_mad_i32_i24") == 0 and count("v_mul_i32_i24") == 0, (count("v_mad_i32_i24"), count("v_mul_i32_i24"))
     assert count("ds_write_b8") == 64
     assert count("v_floor_f32") == 112 and count("v_min3_f32") == 32
     assert count("s_barrier") <= 4, count("s_barrier")

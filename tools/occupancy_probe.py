@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How does k_encode_dense react to occupancy?  Same kernel, LDS bit image enlarged so that fewer workgroups fit per CU
-(96 VGPRs allow 5 four-wave workgroups; LDS per workgroup = 25,920 B at the default 1,024 image words)."""
+(96 VGPRs allow 5 four-wave workgroups; LDS per workgroup = 22,656 B at quality 12's default of 512 image words)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,9 +11,9 @@ enc = Mpeg1Encoder(W, H, 12, "full", max_frames=n)
 rgb = enc.synth(n)
 for _ in range(60):                      # past the clock ramp
     enc.encode(rgb)
-for words in (1024, 2900, 5000, 11000, 1024):
+for words in (512, 3060, 5100, 8530, 512):
     enc.debug_set_lds_words(words)
-    lds = 25920 + (words - 1024) * 4
+    lds = 22656 + (words - 512) * 4
     for _ in range(3):
         enc.encode(rgb)
     torch.cuda.synchronize()

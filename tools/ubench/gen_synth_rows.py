@@ -122,6 +122,44 @@ build("flt_den", [lambda s: colour_flt(s, "and"), row_flt, col_flt, quant_flt])
 for nm in ("int_cvt", "flt_cvt"):
     s = S(); s.l = variants[nm].l[:]; random.shuffle(s.l); variants[nm + "_shuffled"] = s
 
+# the same instructions again, ordered for the issue model of profiles/r02_valu_stream_mix.txt: every half-rate op
+# (cvt / floor / min3 / cmp / mul24: "S") directly followed by a float op ("F"), integer ops ("I") only between float ops
+def klass(op):
+    o = op.split()[0]
+    if o.startswith(("v_cvt", "v_floor", "v_max3", "v_cmp", "v_mul_i32_i24", "v_mad_i32_i24")): return "S"
+    if o.endswith("_f32"): return "F"
+    return "I"
+def paired(ops, style):
+    S_, F_, I_ = ([o for o in ops if klass(o) == k] for k in "SFI")
+    out = []
+    if style == "sf":          # S F S F ... then the remaining F with the I ops spread among them
+        while S_ and F_: out += [S_.pop(0), F_.pop(0)]
+        out += S_
+        rest = F_[:]
+        step = max(1, len(rest) // (len(I_) + 1))
+        for i, o in enumerate(rest):
+            out.append(o)
+            if I_ and i % step == step - 1 and i + 1 < len(rest): out.append(I_.pop(0))
+        out += I_
+    elif style == "sff":       # S F F S F F ... (as many F as there are) then I at the end
+        per = max(1, len(F_) // max(1, len(S_)))
+        while S_:
+            out.append(S_.pop(0))
+            for _ in range(per):
+                if F_: out.append(F_.pop(0))
+        out += F_ + I_
+    elif style == "si":        # worst case by the model: I ops next to S ops
+        while S_ and I_: out += [S_.pop(0), I_.pop(0)]
+        out += S_ + F_ + I_
+    elif style == "blocks":    # all S, then all F, then all I
+        out = S_ + F_ + I_
+    return out
+for st in ("sf", "sff", "si", "blocks"):
+    s = S(); s.l = paired(variants["flt_cvt"].l, st); variants["flt_cvt_" + st] = s
+# rotated copies of the natural order: waves of one SIMD run the same stream at different phases
+ROT = 5
+base_l = variants["flt_cvt"].l
+
 out = ['// GENERATED by gen_synth_rows.py - synthetic per-row instruction streams, see that file.',
        '#include <hip/hip_runtime.h>', '#include <stdio.h>',
        'template <int P> __global__ __launch_bounds__(256) void k(int iters, unsigned *out) {',
@@ -130,6 +168,14 @@ names = list(variants)
 for i, nm in enumerate(names):
     out.append(f'    if (P == {i}) for (int it = 0; it < iters; it++) asm volatile("{variants[nm].text()}" : ' +
                ", ".join(f'"+v"(v[{j}])' for j in range(12)) + ' : "v"(c0), "v"(c1), "v"(w0), "v"(w1), "v"(w2), "v"(w3) : "vcc");')
+nrot = len(names)
+out.append(f'    if (P == {nrot}) {{ const int ph = blockIdx.x % {ROT};')
+for r in range(ROT):
+    k = len(base_l) * r // ROT
+    t = S(); t.l = base_l[k:] + base_l[:k]
+    out.append(f'      if (ph == {r}) for (int it = 0; it < iters; it++) asm volatile("{t.text()}" : ' +
+               ", ".join(f'"+v"(v[{j}])' for j in range(12)) + ' : "v"(c0), "v"(c1), "v"(w0), "v"(w1), "v"(w2), "v"(w3) : "vcc");')
+out.append('    }')
 out += ['    unsigned x = 0; for (int i = 0; i < 12; i++) x ^= v[i]; out[blockIdx.x * 256 + threadIdx.x] = x;', '}',
         'template <int P> void run(const char *name, int n, int waves, unsigned *d) {',
         '    const int iters = 2000, blocks = 256 * waves;', '    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);',
@@ -142,6 +188,9 @@ out += ['    unsigned x = 0; for (int i = 0; i < 12; i++) x ^= v[i]; out[blockId
 for w in (5,):
     for i, nm in enumerate(names):
         out.append(f'    run<{i}>("{nm}", {len(variants[nm].l)}, {w}, d);')
+out.append(f'    run<{nrot}>("flt_cvt_rotated_per_block", {len(base_l)}, 5, d);')
+for i, nm in enumerate(names):
+    if nm.startswith("flt_cvt"): out.append(f'    run<{i}>("{nm} (1 wave)", {len(variants[nm].l)}, 1, d);')
 out += ['    return 0;', '}']
 open(__file__.replace("gen_synth_rows.py", "synth_rows.hip"), "w").write("\n".join(out) + "\n")
 for nm in names: print(nm, len(variants[nm].l))
