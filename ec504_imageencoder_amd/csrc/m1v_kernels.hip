@@ -578,8 +578,9 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
 }
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 8; i++) {
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
+    }
 }
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
@@ -981,12 +982,41 @@ void k_encode_dense(DenseArgs a) {
         const int strip = valid ? s0 + (in_b ? 1 : 0) : g.n_strips - 1;
         const int bidx = valid ? (in_b ? tid - nA : pos0 + tid) : bps - 1;
         src = block_source(g, strip, bidx);
+#if defined(M1V_EXP) && M1V_EXP == 9 // timing experiment: the four waves of a workgroup read four ADJACENT strips at one height
+        {
+            const int groups = g.n_strips / 4, q = run % groups, v = run / groups;
+            src = block_source(g, 4 * q + wave, min(v * 64 + lane, bps - 1));
+        }
+#endif
 #if defined(M1V_EXP) && M1V_EXP == 2 // timing experiment (tools/ab.py --nocheck): no pixel loads at all -> what the arithmetic alone costs
         if constexpr (FAST == 1) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
 #pragma unroll
                 for (int k = 0; k < 6; k++) raw[i].d[k] = (uint32_t)tid * 2654435761u + i * 40503u + k * 9973u + run;
+        }
+#elif defined(M1V_EXP) && M1V_EXP == 1 // timing experiment: same bytes per lane from perfectly coalesced (wrong) addresses
+        if constexpr (FAST == 1) {
+            BlockSrc fake;
+            fake.first = (uint32_t)(((unsigned long long)(run * T + tid) * 64ull) % (unsigned long long)(g.W * (g.H - 8)));
+            fake.stride = 8u; // the lane's eight rows lie behind each other: 192 contiguous bytes per lane, lanes adjacent
+            fake.blk = src.blk;
+            load_block_rows(fbase, fake, raw);
+        }
+#elif defined(M1V_EXP) && M1V_EXP == 7 // timing experiment: every load instruction of a wave reads 64 x 24 contiguous bytes
+        if constexpr (FAST == 1) {
+            BlockSrc fake;
+            const unsigned long long wave_base = ((unsigned long long)(run * (T >> 6) + wave) * 64ull * 64ull) % (unsigned long long)(g.W * (g.H - 16));
+            fake.first = (uint32_t)wave_base + (uint32_t)lane * 8u; // row i of the wave: 64 lanes x 8 pixels behind each other
+            fake.stride = 512u;
+            fake.blk = src.blk;
+            load_block_rows(fbase, fake, raw);
+        }
+#elif defined(M1V_EXP) && M1V_EXP == 4 // timing experiment: every lane's rows from its macroblock's Y0 (fewer distinct lines per wave)
+        if constexpr (FAST == 1) {
+            BlockSrc fake = src;
+            fake.first = src.first - (src.first % 16u);
+            load_block_rows(fbase, fake, raw);
         }
 #else
         if (FAST) load_block_rows(fbase, src, raw);
@@ -1032,7 +1062,9 @@ void k_encode_dense(DenseArgs a) {
     uint32_t incl = wave_scan_inclusive((uint32_t)bb.tot);
     if (lane == kWave - 1) wave_sums[wave] = incl;
     if (tid == nA - 1) wave_sums[16] = incl;       // prefix inside the wave that holds segment 0's last lane
+#if !(defined(M1V_EXP) && M1V_EXP == 8) // timing experiment: no barriers on the common path (wrong results)
     __syncthreads();
+#endif
     const int nw = T >> 6;
     uint32_t wsum = lane < nw ? wave_sums[lane] : 0;
     uint32_t wincl = row_scan_inclusive(wsum);
@@ -1106,7 +1138,9 @@ void k_encode_dense(DenseArgs a) {
     }
     if (valid) put_block<false>(image, off, bb, walk);
     STAMP(6);
+#if !(defined(M1V_EXP) && M1V_EXP == 8)
     __syncthreads();
+#endif
     STAMP(7);
     for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);

@@ -27,6 +27,10 @@ OPS = {
     "U": "v_mul_u32_u24 {d}, {d}, %{k0}",
     "h": "v_mul_hi_i32_i24 {d}, {d}, %{k0}",
     "K": "v_mul_i32_i24 {d}, 0xb5, {d}",
+    "P": "v_perm_b32 {d}, {d}, %{k0}, %{k1}",
+    "X": "v_fma_mix_f32 {d}, {d}, %{k0}, %{k1} op_sel_hi:[1,0,0]",
+    "Y": "v_fma_mix_f32 {d}, {d}, %{k0}, %{k1} op_sel:[1,0,0] op_sel_hi:[1,0,0]",
+    "R": "v_lshrrev_b32 {d}, 8, {d}",
 }
 tests = []
 def t(name, pattern, regs=12, waves=5, reps=None):
@@ -127,6 +131,21 @@ t("  row step, u -> q", step.replace("u", "q"), reps=1)
 t("  row step, u -> +", step.replace("u", "+"), reps=1)
 t("  row step, r -> s", step.replace("r", "s"), reps=1)
 
+# colour conversion with the bytes taken as f16 denormals by v_fma_mix_f32 (2 bytes per v_perm_b32) instead of cvt + fma
+mix_pair = "PPP" + "XYXYXY" + "ns" + "ns" + "x"                  # two pixels: 3 perms, 6 mixed fmas
+mix_pair_and = "NRN" * 1 + "NN" + "XYXYXY" + "ns" + "ns" + "x"     # two pixels = 1.5 dwords: and / shift+and unpack (~4.5 ops)
+t("colour pair (cvt + fma), reference", "cccfffnscccfffnsx")
+t("colour pair, perm + fma_mix", mix_pair)
+t("colour pair, and/shift + fma_mix", mix_pair_and)
+t("only X (fma_mix)", "X")
+t("only P (perm)", "P")
+t("PX", "PX")
+t("Xf", "Xf")
+t("Xa", "Xa")
+colour_mix = "".join(mix_pair for _ in range(4)) + "p"
+t("row step, cvt colour (reference)", colour + row.replace("u", "q") + col + quant, reps=1)
+t("row step, perm + fma_mix colour", colour_mix + row.replace("u", "q") + col + quant, reps=1)
+
 out = ['// GENERATED by gen_stream_probe.py, see that file.', '#include <hip/hip_runtime.h>', '#include <stdio.h>',
        'template <int P> __global__ __launch_bounds__(256) void k(int iters, unsigned *out) {',
        '    unsigned v[12]; for (int i = 0; i < 12; i++) v[i] = threadIdx.x + i; unsigned c0 = 12345, c1 = 77;']
@@ -144,7 +163,7 @@ out += ['    unsigned x = 0; for (int i = 0; i < 12; i++) x ^= v[i]; out[blockId
         '    printf("%-52s %d waves  %3d instr (%3d half-rate)  %7.1f cycles@2GHz  %5.2f per instr   sum model %4d  overlap model %4d\\n", name, waves, n, nS, cyc, cyc / n, nS * 4 + (n - nS) * 2, nS * 4 > (n - nS) * 2 ? nS * 4 : n * 2);',
         '}', 'int main() {', '    unsigned *d; (void)hipMalloc(&d, 256 * 1024 * 8 * 4);', '    run<9>("warm", 1, 0, 4, d); run<9>("warm", 1, 0, 4, d);']
 for i, (name, pat, regs, waves) in enumerate(tests):
-    nS = sum(pat.count(c) for c in "cxlijupqMUhK")
+    nS = sum(pat.count(c) for c in "cxlijupqMUhKPXY")
     out.append(f'    run<{i}>("{name}", {len(pat)}, {nS}, {waves}, d);')
 out += ['    return 0;', '}']
 open(__file__.replace("gen_stream_probe.py", "stream_probe.hip"), "w").write("\n".join(out) + "\n")
