@@ -577,10 +577,29 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
     return r;
 }
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
+#if defined(M1V_LOAD_SPLIT) // experiment: all eight 16-byte heads first, then the eight 8-byte tails
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 head[8];
+    u32x2 tail[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        head[r] = *reinterpret_cast<const u32x4 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        tail[r] = *reinterpret_cast<const u32x2 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u) + 16);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        raw[r].d[0] = head[r].x; raw[r].d[1] = head[r].y; raw[r].d[2] = head[r].z; raw[r].d[3] = head[r].w;
+        raw[r].d[4] = tail[r].x; raw[r].d[5] = tail[r].y;
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
     }
+#endif
 }
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
@@ -962,6 +981,20 @@ void k_encode_dense(DenseArgs a) {
     const bool in_b = tid >= nA;                    // lane belongs to segment 1 (strip s0 + 1)
     const bool has_b = first + nA < nb && nA < T;
 
+    // ---- where this lane's block lies: before any vector load is in flight.  (With the table loads issued first, the
+    //      compiler's v_mad_u64_u32 of the block arithmetic took the register of a pending table word as the unused upper
+    //      half of its 64-bit addend, and every pixel load waited for that word: one full memory latency per workgroup.)
+    BlockSrc src;
+    using RowT = typename std::conditional<FAST == 3, Row32, typename std::conditional<FAST == 2, Row28, Row24>::type>::type;
+    RowT raw[8];
+    {
+        // a run touches at most two strips (T <= blocks per strip), so the lane's strip needs no division; lanes past the
+        // end of the frame (last run only) re-load the frame's last block
+        const int strip = valid ? s0 + (in_b ? 1 : 0) : g.n_strips - 1;
+        const int bidx = valid ? (in_b ? tid - nA : pos0 + tid) : bps - 1;
+        src = block_source(g, strip, bidx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- table loads first, then every pixel load of this lane's block: the in-order vmcnt lets the
     //      tables be consumed while the pixels are still in flight ----
     uint32_t vlcv[kVlcWords / kWave];
@@ -973,15 +1006,7 @@ void k_encode_dense(DenseArgs a) {
     // Every lane loads (lanes past the end of the frame — last run only — re-load the frame's last block): outside any
     // branch the sixteen loads stay countable, so the waits for the table words below are vmcnt(16) and the rows are
     // consumed as they arrive (vmcnt(14), (12), ...) instead of after the last one.
-    BlockSrc src;
-    using RowT = typename std::conditional<FAST == 3, Row32, typename std::conditional<FAST == 2, Row28, Row24>::type>::type;
-    RowT raw[8];
     {
-        // a run touches at most two strips (T <= blocks per strip), so the lane's strip needs no division; lanes past the
-        // end of the frame (last run only) re-load the frame's last block
-        const int strip = valid ? s0 + (in_b ? 1 : 0) : g.n_strips - 1;
-        const int bidx = valid ? (in_b ? tid - nA : pos0 + tid) : bps - 1;
-        src = block_source(g, strip, bidx);
 #if defined(M1V_EXP) && M1V_EXP == 9 // timing experiment: the four waves of a workgroup read four ADJACENT strips at one height
         {
             const int groups = g.n_strips / 4, q = run % groups, v = run / groups;
