@@ -100,19 +100,18 @@ def pmc_traffic(rec):
 
 
 def valu_roofline(rec, kernel_ms):
-    """The resource that actually binds the dominant kernel (profiles/r02_*: without its pixel loads the kernel runs only
-    ~10 % faster): vector-ALU issue.  achieved = (vector instructions per launch, PMC) x (issue cycles per instruction,
-    weighted over the kernel's static class mix with the per-class costs measured by tools/ubench) / live kernel time;
-    peak = SIMDs x shader clock under this load (PMC: GRBM_GUI_ACTIVE / 8 / kernel time of the same pass)."""
+    """How much of the kernel's time vector-ALU issue alone accounts for: (vector instructions per launch, PMC) x (what one
+    instruction of the kernel's own compiled stream costs a SIMD when nothing else is in the way: that stream looped
+    without memory at 5 waves per SIMD, profiles/r02_real_stream.txt) / SIMDs, against the live kernel time.  The rest of
+    the time is exposed memory latency at 5 waves per SIMD (without its pixel loads the kernel runs 13-15 % faster,
+    profiles/r02_ab_history.txt) and workgroup turnover; DESIGN.md, "Where the time goes"."""
     if not rec or "valu" not in rec or kernel_ms <= 0:
         return None
     v = rec["valu"]
-    issue_cycles = v["insts_per_launch"] * v["issue_cycles_per_inst"]
-    peak = v["simds"] * v["clock_ghz"] * 1e9
-    achieved = issue_cycles / (kernel_ms * 1e-3)
-    return {"bound": "valu-issue", "achieved": round(achieved / 1e12, 4), "peak": round(peak / 1e12, 4),
-            "unit": "T issue-cycles/s", "frac": round(achieved / peak, 4), "insts_per_launch": v["insts_per_launch"],
-            "issue_cycles_per_inst": v["issue_cycles_per_inst"], "clock_ghz": v["clock_ghz"], "source": v.get("source", "")}
+    issue_ms = v["insts_per_launch"] * v["ns_per_inst_per_simd"] * 1e-6 / v["simds"]
+    return {"bound": "valu-issue", "achieved": round(issue_ms, 4), "peak": round(kernel_ms, 4), "unit": "ms of issue per ms of kernel",
+            "frac": round(issue_ms / kernel_ms, 4), "insts_per_launch": v["insts_per_launch"],
+            "ns_per_inst_per_simd": v["ns_per_inst_per_simd"], "simds": v["simds"], "source": v.get("source", "")}
 
 
 def cli_bench(args):
@@ -362,14 +361,14 @@ def main():
                        "parallelism": f"frames sharded {n}/GPU" + (
                            (", grouped send/recv of the bitstreams to rank 0 (RCCL)" if args.gather == "xgmi" else
                             ", every rank copies its bitstream into its slice of one pinned host buffer") if distributed else "")},
-            # "hbm" is the roofline BASELINE.json prices the path against; the resource that binds the kernel today is
-            # vector-ALU issue: see "valu" (and DESIGN.md, "Where the time goes")
+            # "hbm" is the roofline BASELINE.json prices the path against.  What the time is made of today: vector-ALU issue
+            # ("valu": ~0.8 of the kernel time) plus memory latency that 5 waves per SIMD do not hide
             "roofline": {"bound": "hbm", "kernel": "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(pmc),
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
                          "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,
                          "kernel_ms_max": round(max(kernel_times), 4) if kernel_times else None, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "valu-issue",
+                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "valu-issue + exposed load latency (5 waves/SIMD; L1 stalled on pending fills 61 % of cycles)",
                          "valu": valu_roofline(pmc, k_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -2,11 +2,11 @@
 // fp32 arithmetic that is EXACT, shared by the device code (m1v_kernels.hip) and the host-side proof
 // (tools/fdct_f32_proof.cpp, tests/test_host_tables.py).
 //
-// Why floats for an integer transform: on gfx950 the kernel is bound by vector-ALU issue, not by memory (with the
-// pixel loads removed it runs 6 % faster, profiles/r02_*).  Integer add/logic instructions cannot issue beside the
-// half-rate conversion/compare unit, float add/mul/fma can (tools/ubench/valu_ports2.hip), and a float fma replaces
-// the two-slot v_mad_i32_i24.  The same butterfly network in fp32 measures 22 % fewer cycles in a synthetic stream of the
-// kernel's instruction mix (tools/ubench/synth_rows.hip).
+// Why floats for an integer transform: the round-1 butterflies were built on v_mad_i32_i24 / v_mul_i32_i24, and a 24-bit
+// integer multiply costs 20-45 cycles inside a mixed instruction stream on gfx950 (tools/ubench/stream_probe.hip,
+// profiles/r02_stream_probe.txt) where a float fma costs ~2.  The same butterfly network in fp32 measures 22 % fewer cycles
+// in a synthetic stream of the kernel's instruction mix (tools/ubench/synth_rows.hip), and 4 % in the kernel (x1.105 ->
+// x1.148 of round 1, profiles/r02_ab_history.txt).
 //
 // Why it is exact: every value the network holds is  N * 2^-s  with an integer |N| < 2^24 (s = 0, 10 or 13), so
 // every add, multiply and fma below returns its exact result without rounding:

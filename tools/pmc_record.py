@@ -8,12 +8,12 @@ From the counters of k_encode_dense:
   fetch_size_kib, write_size_kib   per launch (FETCH_SIZE / WRITE_SIZE are in KiB)
   valu.insts_per_launch            SQ_INSTS_VALU
   valu.clock_ghz                   GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same pass (kernel-trace CSV)
-and from the code object itself (hipcc -S of the shipped source):
-  valu.issue_cycles_per_inst       mean issue cost over the vector instructions of the kernel's common path (basic blocks
-                                   without fp64 instructions, i.e. without the rare exact colour re-evaluation), 2 cycles
-                                   for full-rate classes, 4 for the half-rate ones (tools/ubench/valu_rates.hip:
-                                   conversions, compares, floor/rndne, min3/max3, 24-bit and 64-bit multiplies, bfe/bfi/perm,
-                                   v_cndmask, three-operand integer ops, every fp64 op)"""
+and from a measurement of the kernel's own instruction stream (tools/ubench/gen_real_stream.py -> profiles/r02_real_stream.txt:
+the vector instructions of the compiled pixel stage, same order / registers / dependencies, looped without memory, 5 waves/SIMD):
+  valu.ns_per_inst_per_simd        what ONE vector instruction of this stream costs a SIMD when nothing else is in the way
+                                   (half-rate classes run beside float ops of other instructions: the cost is per
+                                   instruction, ~2.15 cycles at 2 GHz, not the sum of class costs round 2 first assumed)
+  valu.static_mix_common_path      for the record: full-rate / half-rate instruction counts of the common path"""
 import collections
 import csv
 import glob
@@ -58,6 +58,15 @@ def issue_cost_of_common_path(kernel="k_encode_denseILi1ELb1"):
     return cyc / n, {"full_rate_2_cycles": mix[2], "half_rate_4_cycles": mix[4]}
 
 
+def stream_cost_ns():
+    """profiles/r02_real_stream.txt, line of 5 waves/SIMD: cycles at 2.0 GHz per instruction -> ns"""
+    for l in open(os.path.join(ROOT, "profiles", "r02_real_stream.txt")):
+        m = re.search(r"as compiled\s+5 waves/SIMD\s+\d+ instr\s+[\d.]+ cycles@2GHz per pass\s+([\d.]+) per instr", l)
+        if m:
+            return round(float(m.group(1)) / 2.0, 4)
+    raise SystemExit("profiles/r02_real_stream.txt: no 5-wave line")
+
+
 def read_dir(d):
     acc = collections.defaultdict(list)
     dur = []
@@ -90,9 +99,10 @@ def main():
         rec = {"width": W, "height": H, "frames": n, "fetch_size_kib": mean["FETCH_SIZE"], "write_size_kib": mean["WRITE_SIZE"],
                "kernel_us_under_profiler": round(dur * 1e6, 1), "source_dir": os.path.basename(d.rstrip("/"))}
         if "SQ_INSTS_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
-            rec["valu"] = {"insts_per_launch": int(mean["SQ_INSTS_VALU"]), "issue_cycles_per_inst": round(cost, 3), "simds": 1024,
+            rec["valu"] = {"insts_per_launch": int(mean["SQ_INSTS_VALU"]), "ns_per_inst_per_simd": stream_cost_ns(), "simds": 1024,
                            "clock_ghz": round(mean["GRBM_GUI_ACTIVE"] / 8 / dur / 1e9, 3), "static_mix_common_path": mix,
-                           "source": "rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE on the shipped kernel; class costs from tools/ubench/valu_rates.hip"}
+                           "source": "rocprofv3 --pmc SQ_INSTS_VALU on the shipped kernel; cost per instruction from the kernel's own "
+                                     "instruction stream looped without memory at 5 waves per SIMD (profiles/r02_real_stream.txt)"}
         recs.append(rec)
     # GRBM_GUI_ACTIVE / 8 / duration reads high on dispatches well below a millisecond (MI355X_MICROARCH.md, DVFS give-back):
     # take the shader clock of this kernel from the longest dispatch measured and use it for every workload
