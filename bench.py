@@ -6,8 +6,16 @@
 A step = one pass of the hot path over one batch of synthetic frames that are already resident in
 HBM (BASELINE.json configs[2]: 300 x 1920x1080, FULL region, quality factor 12): RGB in, contiguous
 frame records out (also in HBM).  For N > 1 every rank encodes its own 300 frames (global frame
-indices rank*300 ...) and the per-rank bitstreams are gathered on rank 0 with RCCL inside the step.
-Rank 0 prints ONE JSON line.
+indices rank*300 ...); the step loop is ec504_imageencoder_amd.sharding.StepPipeline: the encode of
+step k on the main stream, the exchange of step k-1's bitstreams on a side stream (--gather xgmi:
+grouped send/recv to rank 0 over RCCL; --gather host: every rank copies its bitstream into its slice
+of one pinned host buffer), one host wait per step on eight pinned bytes per rank, nothing allocated
+inside the loop.  Rank 0 prints ONE JSON line.
+
+The line's `roofline` prices the dominant kernel (k_encode_dense) against HBM with its time from HIP events
+recorded on the launch stream inside the library (per launch: min / median / max), carries the HBM bytes of
+the committed PMC passes (`traffic`), and says what the time is made of (`binding`, `valu`): see DESIGN.md,
+"Where the time goes".  `cpu_baseline` is the oracle timed on this box's host cores (bounded samples).
 """
 import argparse
 import json
