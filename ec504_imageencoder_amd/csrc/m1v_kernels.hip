@@ -594,6 +594,19 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
         raw[r].d[0] = head[r].x; raw[r].d[1] = head[r].y; raw[r].d[2] = head[r].z; raw[r].d[3] = head[r].w;
         raw[r].d[4] = tail[r].x; raw[r].d[5] = tail[r].y;
     }
+#elif defined(M1V_EXP) && M1V_EXP == 10 // timing experiment: the 8-byte tail only for blocks 0, 2 and 4 of a macroblock (the others
+                                          // would take it from their left neighbour's registers); the rest read one shared address
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const bool need_tail = (src.blk & 1) == 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *p = fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u);
+        const u32x2 t = *reinterpret_cast<const u32x2 *>(need_tail ? p + 16 : fbase);
+        const u32x4 h = *reinterpret_cast<const u32x4 *>(p);
+        raw[i].d[0] = h.x; raw[i].d[1] = h.y; raw[i].d[2] = h.z; raw[i].d[3] = h.w;
+        raw[i].d[4] = t.x; raw[i].d[5] = t.y;
+    }
 #else
 #pragma unroll
     for (int i = 0; i < 8; i++) {
