@@ -607,6 +607,24 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
         raw[i].d[0] = h.x; raw[i].d[1] = h.y; raw[i].d[2] = h.z; raw[i].d[3] = h.w;
         raw[i].d[4] = t.x; raw[i].d[5] = t.y;
     }
+#elif defined(M1V_LOAD_SHAPE) // experiment: the same 24 bytes per row by other load instructions (results unchanged)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint8_t *p = fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u);
+#if M1V_LOAD_SHAPE == 1   // 8 + 8 + 8
+        const u32x2 a = *reinterpret_cast<const u32x2 *>(p), b = *reinterpret_cast<const u32x2 *>(p + 8), c = *reinterpret_cast<const u32x2 *>(p + 16);
+        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = b.x; raw[i].d[3] = b.y; raw[i].d[4] = c.x; raw[i].d[5] = c.y;
+#elif M1V_LOAD_SHAPE == 2 // 16 + 16, the second overlapping the first by 8 bytes
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(p), b = *reinterpret_cast<const u32x4 *>(p + 8);
+        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = a.z; raw[i].d[3] = a.w; raw[i].d[4] = b.z; raw[i].d[5] = b.w;
+#else                     // 12 + 12
+        const u32x3 a = *reinterpret_cast<const u32x3 *>(p), b = *reinterpret_cast<const u32x3 *>(p + 12);
+        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = a.z; raw[i].d[3] = b.x; raw[i].d[4] = b.y; raw[i].d[5] = b.z;
+#endif
+    }
 #else
 #pragma unroll
     for (int i = 0; i < 8; i++) {
