@@ -327,6 +327,13 @@ __device__ __forceinline__ BlockSrc block_source(const Geometry &g, int strip, i
     return s;
 }
 
+#if defined(M1V_EXP) && M1V_EXP == 11 // timing experiment: HALF a block per lane (4 rows, 4 columns; the other half faked from the
+                                      // own rows): what a two-lanes-per-block mapping would run per lane, to read the occupancy gain
+constexpr int kHalf = 4;
+#else
+constexpr int kHalf = 8;
+#endif
+
 // raw pixels of one block -> the 64 quantised levels, natural order q[u*8+i] (BASELINE config 2 kernel)
 template <bool FAST>
 __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint8_t *frame,
@@ -628,6 +635,9 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
 #else
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+#if defined(M1V_EXP) && M1V_EXP == 11
+        if (i >= 4) continue;
+#endif
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
     }
 #endif
@@ -684,7 +694,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < kHalf; i++) {
         float px[8];
         if constexpr (FAST == 3) {
             if (i == 1) { // rows 4..7: requested once row 0 has been consumed
@@ -710,10 +720,12 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     int dc = 0;
     lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blk;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < kHalf; i++) {
         float c[8];
-        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+        constexpr int kOff = kHalf == 4 ? 4 : 0; // timing experiment: rows 4..7 faked from columns 4..7 of rows 0..3
+        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[(4 % kHalf) * 8 + i + kOff],
+                                rows[(5 % kHalf) * 8 + i + kOff], rows[(6 % kHalf) * 8 + i + kOff], rows[(7 % kHalf) * 8 + i + kOff], c,
+                                i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = quant(c[u], rq_t[i * 8 + u]);
