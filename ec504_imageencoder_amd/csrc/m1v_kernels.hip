@@ -43,9 +43,6 @@
 #include "../../include/mpeg1_hip.h"
 
 #define M1V_HD __host__ __device__ __forceinline__
-#if defined(__HIP_DEVICE_COMPILE__) && defined(M1V_USE_MUL24) // A/B builds only: see fdct_f32.h on why not
-#define M1V_MUL24(a, b) __mul24((a), (b))
-#endif
 #include "fdct_f32.h"
 
 #pragma clang fp contract(off) // colour conversion must stay unfused (image_processing.c:104-106)
@@ -244,11 +241,7 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         out[j + 1] = clear_fraction(t1);
         lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
     }
-#if M1V_EXP == 6 // timing experiment: no rare branch at all
-    if (false) {
-#else
     if (lowest < kFracLow) { // rare: redo the row's flagged pixels in the reference's arithmetic
-#endif
         // Written as a recomputation from the row's bytes (same instructions, same values); on the main path (aligned
         // 3-byte pixels) the compiler instead keeps the eight sums alive across the branch (measured 8 % faster than
         // recomputing: the branch is taken for half of the rows).  The input modes with more raw registers per row (4-byte
@@ -268,12 +261,8 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         for (int j = 0; j < 8; j++) {
             const uint32_t r = chan2(j, 0), gg = chan2(j, 1), b = chan2(j, 2);
             const float t = component_t(r, gg, b, k);
-#if M1V_EXP == 5 // timing experiment: the per-pixel test stays, the fp64 evaluation is replaced by one float op
-            if (t - clear_fraction(t) < kFracLow) out[j] = out[j] - 1.0f;
-#else
             if (t - clear_fraction(t) < kFracLow)
                 out[j] = m1vf::kPxBiasF + (float)component_fp64((int)r, (int)gg, (int)b, d.k0, d.kr, d.kg, d.kb);
-#endif
         }
     }
 }
@@ -327,12 +316,6 @@ __device__ __forceinline__ BlockSrc block_source(const Geometry &g, int strip, i
     return s;
 }
 
-#if defined(M1V_EXP) && M1V_EXP == 11 // timing experiment: HALF a block per lane (4 rows, 4 columns; the other half faked from the
-                                      // own rows): what a two-lanes-per-block mapping would run per lane, to read the occupancy gain
-constexpr int kHalf = 4;
-#else
-constexpr int kHalf = 8;
-#endif
 
 // raw pixels of one block -> the 64 quantised levels, natural order q[u*8+i] (BASELINE config 2 kernel)
 template <bool FAST>
@@ -584,108 +567,13 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
     return r;
 }
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
-#if defined(M1V_LOAD_SPLIT) // experiment: all eight 16-byte heads first, then the eight 8-byte tails
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x4 head[8];
-    u32x2 tail[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-        head[r] = *reinterpret_cast<const u32x4 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-        tail[r] = *reinterpret_cast<const u32x2 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u) + 16);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        raw[r].d[0] = head[r].x; raw[r].d[1] = head[r].y; raw[r].d[2] = head[r].z; raw[r].d[3] = head[r].w;
-        raw[r].d[4] = tail[r].x; raw[r].d[5] = tail[r].y;
-    }
-#elif defined(M1V_EXP) && M1V_EXP == 10 // timing experiment: the 8-byte tail only for blocks 0, 2 and 4 of a macroblock (the others
-                                          // would take it from their left neighbour's registers); the rest read one shared address
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const bool need_tail = (src.blk & 1) == 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint8_t *p = fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u);
-        const u32x2 t = *reinterpret_cast<const u32x2 *>(need_tail ? p + 16 : fbase);
-        const u32x4 h = *reinterpret_cast<const u32x4 *>(p);
-        raw[i].d[0] = h.x; raw[i].d[1] = h.y; raw[i].d[2] = h.z; raw[i].d[3] = h.w;
-        raw[i].d[4] = t.x; raw[i].d[5] = t.y;
-    }
-#elif defined(M1V_LOAD_SHAPE) // experiment: the same 24 bytes per row by other load instructions (results unchanged)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint8_t *p = fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u);
-#if M1V_LOAD_SHAPE == 1   // 8 + 8 + 8
-        const u32x2 a = *reinterpret_cast<const u32x2 *>(p), b = *reinterpret_cast<const u32x2 *>(p + 8), c = *reinterpret_cast<const u32x2 *>(p + 16);
-        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = b.x; raw[i].d[3] = b.y; raw[i].d[4] = c.x; raw[i].d[5] = c.y;
-#elif M1V_LOAD_SHAPE == 2 // 16 + 16, the second overlapping the first by 8 bytes
-        const u32x4 a = *reinterpret_cast<const u32x4 *>(p), b = *reinterpret_cast<const u32x4 *>(p + 8);
-        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = a.z; raw[i].d[3] = a.w; raw[i].d[4] = b.z; raw[i].d[5] = b.w;
-#else                     // 12 + 12
-        const u32x3 a = *reinterpret_cast<const u32x3 *>(p), b = *reinterpret_cast<const u32x3 *>(p + 12);
-        raw[i].d[0] = a.x; raw[i].d[1] = a.y; raw[i].d[2] = a.z; raw[i].d[3] = b.x; raw[i].d[4] = b.y; raw[i].d[5] = b.z;
-#endif
-    }
-#else
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-#if defined(M1V_EXP) && M1V_EXP == 11
-        if (i >= 4) continue;
-#endif
+    for (int i = 0; i < 8; i++)
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
-    }
-#endif
 }
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
 // non-zero mask, one column at a time (nothing but rows[] stays live).  Returns the DC level.
-// ---- tuning aid (tools/mkvariant.sh NAME -DM1V_ABL_CLASS=k, tools/ab.py): pads every block row with 16 extra
-// instructions of one class on a scratch register (results identical) to read the MARGINAL cost of that class in this
-// kernel's instruction mix; class 9 = only the scheduling barrier the padding implies.  0 (default) = nothing.
-#ifndef M1V_ABL_CLASS
-#define M1V_ABL_CLASS 0
-#endif
-#define M1V_REP16(x) x x x x x x x x x x x x x x x x
-__device__ __forceinline__ void abl_pad(uint32_t &d) {
-#if M1V_ABL_CLASS == 1
-    asm volatile(M1V_REP16("v_cvt_f32_ubyte1 %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 2
-    asm volatile(M1V_REP16("v_fma_f32 %0, %0, %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 3
-    asm volatile(M1V_REP16("v_add_u32 %0, %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 4
-    asm volatile(M1V_REP16("v_mad_i32_i24 %0, %0, %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 5
-    asm volatile(M1V_REP16("v_fract_f32 %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 6
-    asm volatile(M1V_REP16("v_cmp_lt_u32 vcc, %0, %0\n") : "+v"(d) : : "vcc");
-#elif M1V_ABL_CLASS == 7
-    asm volatile(M1V_REP16("v_cvt_i32_f32 %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 8
-    asm volatile(M1V_REP16("v_and_b32 %0, %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 9
-    asm volatile("" : "+v"(d));
-#elif M1V_ABL_CLASS == 10
-    asm volatile(M1V_REP16("s_add_u32 s100, s100, 1\n") : "+v"(d) : : "s100", "scc");
-#elif M1V_ABL_CLASS == 11
-    asm volatile(M1V_REP16("s_or_b64 s[100:101], s[100:101], exec\n") : "+v"(d) : : "s100", "s101", "scc");
-#elif M1V_ABL_CLASS == 12
-    asm volatile(M1V_REP16("s_nop 0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 13
-    asm volatile(M1V_REP16("v_mov_b32 %0, %0\n") : "+v"(d));
-#elif M1V_ABL_CLASS == 14
-    asm volatile(M1V_REP16("v_perm_b32 %0, %0, %0, %0\n") : "+v"(d));
-#else
-    (void)d;
-#endif
-}
-
 template <int FAST, bool STAGE8, typename RowT>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
                                               const RowT raw[8], const float *rq_t, uint32_t *blk, uint32_t &lds_addr) {
@@ -694,7 +582,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
 #pragma unroll
-    for (int i = 0; i < kHalf; i++) {
+    for (int i = 0; i < 8; i++) {
         float px[8];
         if constexpr (FAST == 3) {
             if (i == 1) { // rows 4..7: requested once row 0 has been consumed
@@ -709,23 +597,14 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
             load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
         m1vf::fdct_row_f<float>(px, &rows[i * 8]);
-#if M1V_ABL_CLASS
-        {
-            uint32_t abl; // dead after the padding: no register stays live across rows
-            asm volatile("v_mov_b32 %0, 0x3f9d70a4" : "=v"(abl));
-            abl_pad(abl);
-        }
-#endif
     }
     int dc = 0;
     lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blk;
 #pragma unroll
-    for (int i = 0; i < kHalf; i++) {
+    for (int i = 0; i < 8; i++) {
         float c[8];
-        constexpr int kOff = kHalf == 4 ? 4 : 0; // timing experiment: rows 4..7 faked from columns 4..7 of rows 0..3
-        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[(4 % kHalf) * 8 + i + kOff],
-                                rows[(5 % kHalf) * 8 + i + kOff], rows[(6 % kHalf) * 8 + i + kOff], rows[(7 % kHalf) * 8 + i + kOff], c,
-                                i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = quant(c[u], rq_t[i * 8 + u]);
@@ -996,18 +875,8 @@ void k_encode_dense(DenseArgs a) {
     uint32_t *stage = wave_sums + 32;              // T blocks x kStride words
     uint32_t *image = stage + kStride * T;         // a.lds_words
 
-#if defined(M1V_STAGGER) // experiment: start the first generation of workgroups at different phases
-    uint32_t stagger_zero = 0; // stays 0; a plain (non-volatile) asm so that the compiler's view of memory is unchanged
-    if (blockIdx.x < M1V_STAGGER_BLOCKS) {
-        const int ph = (int)((blockIdx.x * 2654435761u) >> 20) % M1V_STAGGER;
-        for (int i = 0; i < ph; i++) asm("s_sleep %1" : "+s"(stagger_zero) : "n"(M1V_STAGGER_SLEEP));
-    }
-#endif
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
-#if defined(M1V_STAGGER)
-    run += (int)stagger_zero;
-#endif
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
     const unsigned long long run_index = (unsigned long long)frame * a.runs_per_frame + run;
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + run_index * a.slot_bytes); // compact slot (common case)
@@ -1050,45 +919,7 @@ void k_encode_dense(DenseArgs a) {
     // branch the sixteen loads stay countable, so the waits for the table words below are vmcnt(16) and the rows are
     // consumed as they arrive (vmcnt(14), (12), ...) instead of after the last one.
     {
-#if defined(M1V_EXP) && M1V_EXP == 9 // timing experiment: the four waves of a workgroup read four ADJACENT strips at one height
-        {
-            const int groups = g.n_strips / 4, q = run % groups, v = run / groups;
-            src = block_source(g, 4 * q + wave, min(v * 64 + lane, bps - 1));
-        }
-#endif
-#if defined(M1V_EXP) && M1V_EXP == 2 // timing experiment (tools/ab.py --nocheck): no pixel loads at all -> what the arithmetic alone costs
-        if constexpr (FAST == 1) {
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int k = 0; k < 6; k++) raw[i].d[k] = (uint32_t)tid * 2654435761u + i * 40503u + k * 9973u + run;
-        }
-#elif defined(M1V_EXP) && M1V_EXP == 1 // timing experiment: same bytes per lane from perfectly coalesced (wrong) addresses
-        if constexpr (FAST == 1) {
-            BlockSrc fake;
-            fake.first = (uint32_t)(((unsigned long long)(run * T + tid) * 64ull) % (unsigned long long)(g.W * (g.H - 8)));
-            fake.stride = 8u; // the lane's eight rows lie behind each other: 192 contiguous bytes per lane, lanes adjacent
-            fake.blk = src.blk;
-            load_block_rows(fbase, fake, raw);
-        }
-#elif defined(M1V_EXP) && M1V_EXP == 7 // timing experiment: every load instruction of a wave reads 64 x 24 contiguous bytes
-        if constexpr (FAST == 1) {
-            BlockSrc fake;
-            const unsigned long long wave_base = ((unsigned long long)(run * (T >> 6) + wave) * 64ull * 64ull) % (unsigned long long)(g.W * (g.H - 16));
-            fake.first = (uint32_t)wave_base + (uint32_t)lane * 8u; // row i of the wave: 64 lanes x 8 pixels behind each other
-            fake.stride = 512u;
-            fake.blk = src.blk;
-            load_block_rows(fbase, fake, raw);
-        }
-#elif defined(M1V_EXP) && M1V_EXP == 4 // timing experiment: every lane's rows from its macroblock's Y0 (fewer distinct lines per wave)
-        if constexpr (FAST == 1) {
-            BlockSrc fake = src;
-            fake.first = src.first - (src.first % 16u);
-            load_block_rows(fbase, fake, raw);
-        }
-#else
         if (FAST) load_block_rows(fbase, src, raw);
-#endif
     }
 
     // ---- workgroup prologue, under the latency of those loads ----
@@ -1108,10 +939,6 @@ void k_encode_dense(DenseArgs a) {
     }
     // No barrier here: pass 1 below reads only the lane's own staged levels and the wave's own copy of the VLC table.
     // The image zeroed in the prologue is first touched in pass 2, behind the barrier of the scan.
-#if defined(M1V_EXP) && M1V_EXP == 3 // timing experiment (tools/ab.py --nocheck): pixel stage only, no entropy coding / packing
-    if (valid) slot32[tid] = (uint32_t)nz ^ (uint32_t)(nz >> 32) ^ (uint32_t)dc;
-    return;
-#endif
     STAMP(2);
     auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(blk, p); };
 
@@ -1130,9 +957,7 @@ void k_encode_dense(DenseArgs a) {
     uint32_t incl = wave_scan_inclusive((uint32_t)bb.tot);
     if (lane == kWave - 1) wave_sums[wave] = incl;
     if (tid == nA - 1) wave_sums[16] = incl;       // prefix inside the wave that holds segment 0's last lane
-#if !(defined(M1V_EXP) && M1V_EXP == 8) // timing experiment: no barriers on the common path (wrong results)
     __syncthreads();
-#endif
     const int nw = T >> 6;
     uint32_t wsum = lane < nw ? wave_sums[lane] : 0;
     uint32_t wincl = row_scan_inclusive(wsum);
@@ -1206,9 +1031,7 @@ void k_encode_dense(DenseArgs a) {
     }
     if (valid) put_block<false>(image, off, bb, walk);
     STAMP(6);
-#if !(defined(M1V_EXP) && M1V_EXP == 8)
     __syncthreads();
-#endif
     STAMP(7);
     for (uint32_t i = tid; i < end_words; i += T) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
