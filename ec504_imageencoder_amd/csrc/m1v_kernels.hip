@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mpeg1_hip.h"
@@ -1125,6 +1126,22 @@ struct GatherArgs {
     int n_frames, n_strips, first_index;
 };
 
+// PKT SEQ GOP PIC in front of a frame's strips with the 16-bit length back-patched (encoder.h:198-230, :448-453:
+// (u16)(bytes after the length field's word) - 4) and the four trailing bytes (encoder.h:456-458, observed zero);
+// threads 0..47 of the workgroup that gathers the frame's first strip
+__device__ __forceinline__ void frame_header_and_trailer(const Tables *tab, uint8_t *out, unsigned long long fo,
+                                                         unsigned long long fs, int index, int t) {
+    if (t < 44) {
+        uint8_t v = tab->hdr[index & 255][t];
+        const uint32_t fwd = (uint32_t)((fs - 4ull) - 4ull - 4ull) & 0xffffu;
+        if (t == 4) v = (uint8_t)(fwd >> 8);
+        if (t == 5) v = (uint8_t)(fwd & 0xff);
+        out[fo + t] = v;
+    } else if (t < 48) {
+        out[fo + fs - 4 + (t - 44)] = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
     int s = blockIdx.x, f = blockIdx.y;
     unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
@@ -1137,19 +1154,7 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
     uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
     uint32_t n = a.strip_bytes[idx];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    if (s == 0) {
-        int t = threadIdx.x;
-        if (t < 44) {
-            uint8_t v = a.tab->hdr[(a.first_index + f) & 255][t];
-            // encoder.h:448-453: (u16)(bytes after the length field's word) - 4
-            uint32_t fwd = (uint32_t)((fs - 4ull) - 4ull - 4ull) & 0xffffu;
-            if (t == 4) v = (uint8_t)(fwd >> 8);
-            if (t == 5) v = (uint8_t)(fwd & 0xff);
-            a.out[fo + t] = v;
-        } else if (t < 48) {
-            a.out[fo + fs - 4 + (t - 44)] = 0; // encoder.h:456-458 (observed zero)
-        }
-    }
+    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
 }
 
 // ---- dense path: strips are concatenations of run segments ----------------------------------------
@@ -1292,19 +1297,10 @@ __global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
             for (uint32_t k = 0; k < 4u && b0 + k < n; k++) o[k] = (uint8_t)(val >> (24u - 8u * k));
         }
     }
-    if (s == 0) {
-        int t = threadIdx.x;
-        if (t < 44) {
-            uint8_t v = a.tab->hdr[(a.first_index + f) & 255][t];
-            uint32_t fwd = (uint32_t)((fs - 4ull) - 4ull - 4ull) & 0xffffu; // encoder.h:448-453
-            if (t == 4) v = (uint8_t)(fwd >> 8);
-            if (t == 5) v = (uint8_t)(fwd & 0xff);
-            a.out[fo + t] = v;
-        } else if (t < 48) {
-            a.out[fo + fs - 4 + (t - 44)] = 0; // encoder.h:456-458 (observed zero)
-        }
-    }
+    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
 }
+
+#include "m1v_tiles.h"
 
 // ------------------------------------------------------------------------------------------------
 // partial pipelines
@@ -1573,12 +1569,23 @@ struct m1v_encoder {
     hipStream_t side;
     bool fast_ok;      // geometry allows the 4-byte-aligned 24-byte row loads
     int forced_mode;   // test hook (m1v_debug_set_input_mode): -1 = pick by geometry and alignment
+    // Which encode kernel serves a batch.  Tiles (k_encode_tiles, m1v_tiles.h): 3-channel pictures, any width and
+    // alignment — the default.  Runs (k_encode_dense / k_encode_strips): 4-channel pictures, and whatever the test
+    // hooks force (m1v_debug_set_path, a forced input mode, a forced run length).
+    int forced_path;   // -1 = by geometry, 0 = runs, 1 = tiles
+    int forced_T;      // run length forced by m1v_debug_set_dense_threads (0 = default)
+    bool tiles;        // the path configure_path set up
+    int tile_cols, tile_rows, tiles_per_frame, tile_ring;
+    uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
+    size_t meta_bytes;      // size of run_meta (runs) or seg (tiles) in effect
     Tables *d_tab;
     // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
     // pipelined mode batch k+1 can encode while batch k is still being gathered.
     struct Batch {
         uint8_t *scratch;
-        uint32_t *run_meta;
+        uint32_t *run_meta;     // runs path
+        uint2 *seg;             // tiles path: [frame][strip][tile row] (bits, where)
+        uint32_t *seg_pre;      //             bit offset of each segment inside its strip
         uint32_t *strip_bytes, *strip_off;
         StripDesc *strip_desc;
         unsigned long long *frame_size, *frame_off;
@@ -1643,53 +1650,117 @@ size_t m1v_file_prolog(uint8_t out[27]) {
     return 27;
 }
 
-// Chooses the encode kernel geometry and (re)allocates its scratch.  dense_T = 0 picks the default
-// run length: 256 blocks (4 waves = one per SIMD, so that 5 workgroups of 96-VGPR waves share a CU; measured
-// 384/320/256/192/128 -> 1140/1161/837/892/1026 us per 300 x 1080p), or the largest multiple of 64 that the
-// strip holds when it has fewer than 256 blocks.
-static int configure_path(m1v_encoder *e, int dense_T) {
+// Chooses the encode kernel and its geometry and (re)allocates its scratch.  e->forced_T: run length of the run kernels
+// (0 = default: 256 blocks = 4 waves, one per SIMD, so that 5 workgroups of 96-VGPR waves share a CU; or the largest
+// multiple of 64 that the strip holds when it has fewer than 256 blocks).
+// New buffers are allocated FIRST and swapped in, together with the geometry they belong to, only when every allocation
+// has succeeded: a failed call (the worst-case arena of m1v_reserve_scratch is large) leaves the encoder as it was.
+#ifndef M1V_TILE_RING
+#define M1V_TILE_RING 4
+#endif
+static int configure_path(m1v_encoder *e) {
+    const int dense_T = e->forced_T;
     const Geometry &g = e->g;
-    int bps = g.n_mbrows * 6;
-    size_t need, meta = 0;
-    if (e->dense) {
+    const int bps = g.n_mbrows * 6;
+    struct {
+        bool tiles;
+        int tile_cols, tile_rows, tiles_per_frame, tile_ring;
+        uint32_t luma_region, chroma_region;
+        int dense_T, runs_per_frame;
+        uint32_t run_cap, slot_bytes, arena_slots;
+        size_t arena_off;
+        int image_words;
+    } plan = {};
+    plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0);
+    size_t need, meta = 0, pre = 0;
+    if (plan.tiles) {
+        plan.tile_cols = (g.n_strips + kTileStrips - 1) / kTileStrips;
+        plan.tile_rows = (g.n_mbrows + kTileMbRows - 1) / kTileMbRows;
+        plan.tiles_per_frame = plan.tile_cols * plan.tile_rows;
+        plan.tile_ring = M1V_TILE_RING;
+        const uint32_t stage = (uint32_t)(kWave * (e->narrow ? kStageStride8 : kStageStride16) * 4);
+        plan.luma_region = (std::max<uint32_t>((uint32_t)plan.tile_ring * kLumaStep, stage) + 15u) & ~15u;
+        plan.chroma_region = (std::max<uint32_t>((uint32_t)plan.tile_ring * kChromaStep, stage) + 15u) & ~15u;
+        // worst case of a tile: 8 word-aligned segments of 24 blocks of <= 886 + 2 bits, 8 slice headers, slack
+        plan.run_cap = (uint32_t)(((((size_t)kTileThreads * (kMaxBlockBits + 2) + kTileStrips * (38 + 32) + 64 + 7) / 8) + 32 + 15) & ~(size_t)15);
+        // LDS image of the tile's bits (192 blocks: ~115 words at quality 12 on noise), scaled with the quantiser like the
+        // run kernels' (512 words per 256 blocks at quality <= 25) + the segments' word alignment and slice headers
+        plan.image_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 400 : (e->qf <= 50 ? 784 : (e->qf <= 76 ? 1552 : 3088)));
+        plan.slot_bytes = (uint32_t)((((size_t)plan.image_words * 4 + 127) & ~(size_t)127) | 128);
+        const size_t runs = (size_t)e->max_frames * plan.tiles_per_frame;
+        plan.arena_slots = (uint32_t)(e->reserve_worst ? runs : (runs / 256 > 32 ? runs / 256 : (runs < 32 ? runs : 32)));
+        plan.arena_off = runs * plan.slot_bytes;
+        need = plan.arena_off + (size_t)plan.arena_slots * plan.run_cap;
+        if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
+        meta = (size_t)e->max_frames * g.n_strips * plan.tile_rows * sizeof(uint2);
+        pre = (size_t)e->max_frames * g.n_strips * plan.tile_rows * sizeof(uint32_t);
+    } else if (e->dense) {
         int T = dense_T > 0 ? dense_T : (bps >= 256 ? 256 : (bps / kWave) * kWave);
         if (T < kWave || T > 384 || T % kWave || T > bps) return fail(M1V_E_ARG, "bad dense run length%s");
-        e->dense_T = T;
+        plan.dense_T = T;
         int nb = g.n_strips * bps;
-        e->runs_per_frame = (nb + T - 1) / T;
+        plan.runs_per_frame = (nb + T - 1) / T;
         // worst case of a run: two word-aligned segments of at most T blocks of <= 886 + 2 bits, two slice headers, slack
-        e->run_cap = (uint32_t)(((((size_t)T * (kMaxBlockBits + 2) + 2 * 38 + 3 * 32 + 7) / 8) + 32 + 15) & ~(size_t)15);
+        plan.run_cap = (uint32_t)(((((size_t)T * (kMaxBlockBits + 2) + 2 * 38 + 3 * 32 + 7) / 8) + 32 + 15) & ~(size_t)15);
         // LDS image of the run's bits: zeroing it costs time, outgrowing it the slow global-atomics path.  A run of 256
         // blocks needs ~150 words at quality 12 on noise; scale the default with the quantiser (finer quantisers emit
         // more bits per block).  The compact scratch slot of a run is exactly that image.
-        e->image_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 512 : (e->qf <= 50 ? 1024 : (e->qf <= 76 ? 2048 : 4096)));
+        plan.image_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 512 : (e->qf <= 50 ? 1024 : (e->qf <= 76 ? 2048 : 4096)));
         // + 128: an odd number of 128-byte lines, so that the slots (of which only the first third is written at quality
         // 12) do not all start on the same few memory channels (a power-of-two stride measured 3 % slower)
-        e->slot_bytes = (uint32_t)((((size_t)e->image_words * 4 + 127) & ~(size_t)127) | 128);
+        plan.slot_bytes = (uint32_t)((((size_t)plan.image_words * 4 + 127) & ~(size_t)127) | 128);
         // Scratch: one compact slot per run + an overflow arena of worst-case slots for the runs whose image outgrows LDS
         // (handed out by an atomic counter).  By default the arena holds 1/256 of the runs (quality 12 noise needs none);
         // m1v_reserve_scratch(enc, 1) sizes it for all of them — what every run had in round 1, 47x the payload.
-        const size_t runs = (size_t)e->max_frames * e->runs_per_frame;
-        e->arena_slots = (uint32_t)(e->reserve_worst ? runs : (runs / 256 > 32 ? runs / 256 : (runs < 32 ? runs : 32)));
-        e->arena_off = runs * e->slot_bytes;
-        need = e->arena_off + (size_t)e->arena_slots * e->run_cap;
+        const size_t runs = (size_t)e->max_frames * plan.runs_per_frame;
+        plan.arena_slots = (uint32_t)(e->reserve_worst ? runs : (runs / 256 > 32 ? runs / 256 : (runs < 32 ? runs : 32)));
+        plan.arena_off = runs * plan.slot_bytes;
+        need = plan.arena_off + (size_t)plan.arena_slots * plan.run_cap;
         if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
         meta = runs * 4 * sizeof(uint32_t);
     } else {
         need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
     }
     const int sets = e->pipelined ? 2 : 1;
+    struct Fresh {
+        uint8_t *scratch;
+        void *meta, *pre;
+        bool new_scratch, new_meta;
+    } fresh[2] = {};
+    bool ok = true;
+    for (int i = 0; i < sets && ok; i++) {
+        const m1v_encoder::Batch &bt = e->batch[i];
+        Fresh &f = fresh[i];
+        f.new_scratch = need != e->scratch_bytes || !bt.scratch;
+        const void *have_meta = plan.tiles ? (const void *)bt.seg : (const void *)bt.run_meta;
+        f.new_meta = meta != 0 && (meta != e->meta_bytes || plan.tiles != e->tiles || !have_meta);
+        if (f.new_scratch) ok = hipMalloc(&f.scratch, need) == hipSuccess;
+        if (ok && f.new_meta) ok = hipMalloc(&f.meta, meta) == hipSuccess;
+        if (ok && f.new_meta && pre) ok = hipMalloc(&f.pre, pre) == hipSuccess;
+    }
+    if (!ok) {
+        for (Fresh &f : fresh) {
+            (void)hipFree(f.scratch);
+            (void)hipFree(f.meta);
+            (void)hipFree(f.pre);
+        }
+        (void)hipGetLastError();
+        return fail(M1V_E_HIP, "scratch allocation failed (the encoder keeps its previous configuration)%s");
+    }
     for (int i = 0; i < sets; i++) {
         m1v_encoder::Batch &bt = e->batch[i];
-        if (need != e->scratch_bytes || !bt.scratch) {
+        Fresh &f = fresh[i];
+        if (f.new_scratch) {
             (void)hipFree(bt.scratch);
-            bt.scratch = nullptr;
-            if (hipMalloc(&bt.scratch, need) != hipSuccess) return fail(M1V_E_HIP, "scratch allocation failed%s");
+            bt.scratch = f.scratch;
         }
-        if (meta) {
+        if (f.new_meta) {
             (void)hipFree(bt.run_meta);
-            bt.run_meta = nullptr;
-            if (hipMalloc(&bt.run_meta, meta) != hipSuccess) return fail(M1V_E_HIP, "metadata allocation failed%s");
+            (void)hipFree(bt.seg);
+            (void)hipFree(bt.seg_pre);
+            bt.run_meta = plan.tiles ? nullptr : (uint32_t *)f.meta;
+            bt.seg = plan.tiles ? (uint2 *)f.meta : nullptr;
+            bt.seg_pre = (uint32_t *)f.pre;
         }
         size_t nslots = (size_t)e->max_frames * g.n_strips;
         if (!bt.strip_bytes) {
@@ -1705,7 +1776,15 @@ static int configure_path(m1v_encoder *e, int dense_T) {
             if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
         }
     }
+    e->tiles = plan.tiles;
+    e->tile_cols = plan.tile_cols; e->tile_rows = plan.tile_rows; e->tiles_per_frame = plan.tiles_per_frame;
+    e->tile_ring = plan.tile_ring;
+    e->luma_region = plan.luma_region; e->chroma_region = plan.chroma_region;
+    e->dense_T = plan.dense_T; e->runs_per_frame = plan.runs_per_frame;
+    e->run_cap = plan.run_cap; e->image_words = plan.image_words; e->slot_bytes = plan.slot_bytes;
+    e->arena_slots = plan.arena_slots; e->arena_off = plan.arena_off;
     e->scratch_bytes = need;
+    e->meta_bytes = meta;
     return M1V_OK;
 }
 
@@ -1754,6 +1833,16 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     memset(&e->hp, 0, sizeof e->hp);
     e->fast_ok = channels == 3 && (width % 8) == 0;
     e->forced_mode = -1;
+    e->forced_path = -1;
+    e->forced_T = 0;
+    e->tiles = false;
+    e->tile_cols = e->tile_rows = e->tiles_per_frame = e->tile_ring = 0;
+    e->luma_region = e->chroma_region = 0;
+    e->meta_bytes = 0;
+    e->runs_per_frame = 0;
+    e->run_cap = e->slot_bytes = e->arena_slots = 0;
+    e->arena_off = 0;
+    e->image_words = 0;
     e->prof = false;
     e->ev_used = 0;
     e->d_stamps = nullptr;
@@ -1781,12 +1870,13 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 16 * 8);
     if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
 #endif
-    if (err == hipSuccess) err = configure_path(e, 0) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
+    if (err == hipSuccess) err = configure_path(e) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
     const void *kernels[] = {(const void *)&k_encode_dense<1, true>, (const void *)&k_encode_dense<1, false>,
                              (const void *)&k_encode_dense<2, true>, (const void *)&k_encode_dense<2, false>,
                              (const void *)&k_encode_dense<3, true>, (const void *)&k_encode_dense<3, false>,
                              (const void *)&k_encode_dense<0, true>, (const void *)&k_encode_dense<0, false>,
-                             (const void *)&k_encode_strips<true>,       (const void *)&k_encode_strips<false>};
+                             (const void *)&k_encode_strips<true>,       (const void *)&k_encode_strips<false>,
+                             (const void *)&k_encode_tiles<true, M1V_TILE_RING>, (const void *)&k_encode_tiles<false, M1V_TILE_RING>};
     for (const void *kf : kernels)
         if (err == hipSuccess) err = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) {
@@ -1806,6 +1896,8 @@ void m1v_destroy(m1v_encoder *e) {
     for (m1v_encoder::Batch &bt : e->batch) {
         (void)hipFree(bt.scratch);
         (void)hipFree(bt.run_meta);
+        (void)hipFree(bt.seg);
+        (void)hipFree(bt.seg_pre);
         (void)hipFree(bt.strip_bytes);
         (void)hipFree(bt.strip_off);
         (void)hipFree(bt.strip_desc);
@@ -1841,19 +1933,22 @@ size_t m1v_frame_bound(const m1v_encoder *e) {
 int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
     e->lds_words = words > 0 ? (words < 4 ? 4 : words) : 0;
-    if (!e->dense) return M1V_OK;
+    if (!e->dense && !e->tiles) return M1V_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    return configure_path(e, e->dense_T); // (a small forced image sends many runs to the overflow arena: M1V_STATUS_SCRATCH)
+    return configure_path(e); // (a small forced image sends many runs to the overflow arena: M1V_STATUS_SCRATCH)
 }
 
 int m1v_reserve_scratch(m1v_encoder *e, int worst_case) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
-    if (!e->dense) return M1V_OK;
+    if (!e->dense && !e->tiles) return M1V_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    const bool before = e->reserve_worst;
     e->reserve_worst = worst_case != 0;
-    return configure_path(e, e->dense_T);
+    const int rc = configure_path(e);
+    if (rc != M1V_OK) e->reserve_worst = before; // the previous arena is still in place
+    return rc;
 }
 
 size_t m1v_scratch_bytes(const m1v_encoder *e) { return e ? e->scratch_bytes * (e->pipelined ? 2 : 1) : 0; }
@@ -1866,7 +1961,7 @@ int m1v_set_pipelined(m1v_encoder *e, int enable) {
     e->pipelined = enable != 0;
     e->calls = 0;
     if (e->pipelined && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    return configure_path(e, e->dense_T);
+    return configure_path(e);
 }
 
 int m1v_flush(m1v_encoder *e, void *stream) {
@@ -1882,8 +1977,10 @@ int m1v_flush(m1v_encoder *e, void *stream) {
 int m1v_debug_set_input_mode(m1v_encoder *e, int mode) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
     if (mode != -1 && mode != 0 && mode != 2) return fail(M1V_E_ARG, "input mode must be -1 (auto), 0 (byte loads) or 2 (funnel)%s");
-    e->forced_mode = mode;
-    return M1V_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    e->forced_mode = mode; // an input mode is a property of the run kernels: forcing one selects them
+    return configure_path(e);
 }
 
 int m1v_debug_set_dense_threads(m1v_encoder *e, int threads) {
@@ -1891,8 +1988,27 @@ int m1v_debug_set_dense_threads(m1v_encoder *e, int threads) {
     if (!e->dense) return M1V_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    return configure_path(e, threads);
+    const int before = e->forced_T;
+    e->forced_T = threads > 0 ? threads : 0; // a run length is a property of the run kernels: forcing one selects them
+    const int rc = configure_path(e);
+    if (rc != M1V_OK) e->forced_T = before;
+    return rc;
 }
+
+int m1v_debug_set_path(m1v_encoder *e, int path) {
+    if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    if (path < -1 || path > 1) return fail(M1V_E_ARG, "path must be -1 (by geometry), 0 (runs) or 1 (tiles)%s");
+    if (path == 1 && e->g.C != 3) return fail(M1V_E_ARG, "the tile kernel takes 3-channel pictures%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int before = e->forced_path;
+    e->forced_path = path;
+    const int rc = configure_path(e);
+    if (rc != M1V_OK) e->forced_path = before;
+    return rc;
+}
+
+int m1v_path_in_use(const m1v_encoder *e) { return e ? (e->tiles ? 1 : 0) : -1; }
 
 #ifdef M1V_STAMPS
 // diagnostic build only: read and clear the per-phase cycle sums
@@ -1991,7 +2107,67 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
 
-    if (e->dense) {
+    if (!bt.scratch || (e->tiles ? !bt.seg || !bt.seg_pre : (e->dense && !bt.run_meta)))
+        return fail(M1V_E_HIP, "the encoder has no scratch (an earlier allocation failed)%s");
+    if (e->tiles) {
+        TileArgs a;
+        a.g = g;
+        a.rgb = d_rgb;
+        a.tab = e->d_tab;
+        a.scratch = bt.scratch;
+        a.seg = bt.seg;
+        a.arena_next = bt.status + 2;
+        a.slot_bytes = e->slot_bytes;
+        a.arena_slots = e->arena_slots;
+        a.arena_off = e->arena_off;
+        a.status = bt.status;
+        a.n_frames = n_frames;
+        a.tile_cols = e->tile_cols;
+        a.tile_rows = e->tile_rows;
+        a.tiles_per_frame = e->tiles_per_frame;
+        a.lds_words = e->image_words;
+        a.run_cap = e->run_cap;
+        a.luma_region = e->luma_region;
+        a.chroma_region = e->chroma_region;
+        const size_t lds = (size_t)kTileFixedWords * 4 + 2 * (size_t)a.luma_region + a.chroma_region + (size_t)a.lds_words * 4;
+        if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
+        dim3 grid((unsigned)((size_t)n_frames * e->tiles_per_frame)), block((unsigned)kTileThreads);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        if (e->narrow)
+            hipLaunchKernelGGL((k_encode_tiles<true, M1V_TILE_RING>), grid, block, lds, st, a);
+        else
+            hipLaunchKernelGGL((k_encode_tiles<false, M1V_TILE_RING>), grid, block, lds, st, a);
+        if (e->prof && profile_event(e, st) != M1V_OK) return M1V_E_HIP;
+        HIP_TRY(hipGetLastError());
+        if (e->pipelined) {
+            HIP_TRY(hipEventRecord(bt.enc_done, st));
+            HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
+        }
+        TileGeom d;
+        d.n_frames = n_frames;
+        d.n_strips = g.n_strips;
+        d.tile_rows = e->tile_rows;
+        hipLaunchKernelGGL(k_tile_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.seg, bt.seg_pre, bt.strip_bytes, bt.strip_off,
+                           bt.frame_size);
+        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
+        TileGatherArgs ga;
+        ga.d = d;
+        ga.scratch = bt.scratch;
+        ga.seg = bt.seg;
+        ga.seg_pre = bt.seg_pre;
+        ga.strip_bytes = bt.strip_bytes;
+        ga.strip_off = bt.strip_off;
+        ga.frame_size = bt.frame_size;
+        ga.frame_off = bt.frame_off;
+        ga.tab = e->d_tab;
+        ga.out = d_out;
+        ga.out_cap = out_cap;
+        ga.status = d_status ? d_status : bt.status + 1;
+        ga.first_index = first_frame_index;
+        hipLaunchKernelGGL(k_gather_tiles, dim3(g.n_strips, n_frames), dim3(kTileGatherThreads),
+                           (size_t)(3 * e->tile_rows + 1) * sizeof(uint32_t), gs, ga);
+        HIP_TRY(hipGetLastError());
+    } else if (e->dense) {
         DenseArgs a;
         a.g = g;
         a.rgb = d_rgb;

@@ -1,0 +1,400 @@
+// ec504_imageencoder_amd/csrc/m1v_tiles.h — the TILE form of the hot kernel (gfx950).  Not a standalone header: it is
+// included by m1v_kernels.hip inside its anonymous namespace, behind the pieces it shares with the run kernels
+// (colour conversion, fp32 FDCT, staging layout, VLC walk, bit packing helpers).
+//
+// Why tiles.  A strip is a 16-pixel wide COLUMN of macroblocks (encoder.h:238 iterates x outermost), i.e. 48 bytes of
+// every 128-byte line of the picture; the run kernels (one lane per block down a strip, 24-byte row loads per lane)
+// touch ~37 lines with every wave load and fetch every line 2.7 times into some L1 (profiles/r02_memory_path_pmc.txt:
+// 4.8 x L1 fills per pixel byte).  Here a workgroup owns a TILE of 8 adjacent strips x 4 macroblock rows
+// (128 x 64 pixels: rows of 384 bytes = three whole lines) and brings it in with LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB of whole lines per wave instruction, no vector registers), through a small ring of
+// row-steps per wave; lanes then take their 24-byte block rows out of LDS.
+//
+//   workgroup = 3 waves = 192 lanes = the tile's 192 blocks (image_processing.c:138-150 extract_8x8_block order does
+//   not matter before the bits are placed):
+//     wave 0, 1   luma: macroblock rows 2w, 2w+1 of the tile.  lane = [mb row:1][block row (Y0Y1 | Y2Y3):1][strip:3][Y left|right:1]
+//                 so row-step i of the wave (row i of each of its 64 blocks) is 4 picture rows x 384 contiguous bytes
+//                 = 1536 bytes, and lane L's 24 bytes sit at L * 24: conflict-free ds_read_b64 x 3.
+//     wave 2      chroma: Cb (lanes 0..31) and Cr (32..63) of the tile's 32 macroblocks; both read the SAME 24 bytes
+//                 (encoder.h:347-348: the full-resolution plane addressed with stride W/2), which arrive once:
+//                 row-step = 4 macroblock rows x 192 bytes.
+//   Row-steps travel in a ring of R slots per wave (wave-private: ordered by the wave's own vmcnt, no barrier); the
+//   staged levels of the wave's blocks later reuse the ring's bytes.
+//
+// Bits.  A tile holds 8 strip SEGMENTS (24 consecutive blocks of the strip's stream each).  Lanes write their block's
+// bit count to LDS in emission order; after ONE barrier every wave scans all 192 counts itself (no second barrier),
+// segments start on word boundaries of the tile's LDS image, and the tile records (bits, where) per segment;
+// k_tile_layout / k_gather_tiles concatenate a strip's segments (encoder.h:442-445).
+
+constexpr int kTileStrips = 8, kTileMbRows = 4;
+constexpr int kTileThreads = kTileStrips * kTileMbRows * 6; // 192
+constexpr int kTileSegBlocks = kTileMbRows * 6;             // 24 blocks of one strip
+constexpr int kLumaStep = 64 * 24, kChromaStep = 32 * 24;   // bytes of one row-step of a luma / the chroma wave
+// LDS words in front of the per-wave regions: VLC table, bit counts, prefix sums (+ total), segment table, spare
+constexpr int kTileVlc = 0, kTileCnt = 192, kTileG = 384, kTileSegTab = 580, kTileMisc = 596, kTileFixedWords = 600;
+
+struct TileArgs {
+    Geometry g;
+    const uint8_t *rgb;
+    const Tables *tab;
+    uint8_t *scratch;       // [frame][tile][slot_bytes] compact slots, then the overflow arena (as the run kernels)
+    uint2 *seg;             // [frame][strip][tile row]: bits of the segment, where it starts (4-byte words from `scratch`)
+    uint32_t *arena_next;
+    uint32_t slot_bytes, arena_slots;
+    unsigned long long arena_off;
+    uint32_t *status;
+    int n_frames;
+    int tile_cols, tile_rows, tiles_per_frame;
+    int lds_words;          // capacity of the LDS image of the tile's bits
+    uint32_t run_cap;       // bytes of one arena slot: the worst case of a tile
+    uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
+};
+
+#define M1V_CONST_AS __attribute__((address_space(4)))
+
+// One LDS-DMA instruction: 16 bytes per active lane from (sbase + voff) to LDS (ldsdst + 16 * lane).  M0 carries the
+// destination and is the compiler's: saved and restored inside the statement (cdna_hip_programming.md, inline asm).
+__device__ __forceinline__ void dma16(uint32_t voff, uint32_t ldsdst, const uint8_t *sbase) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(ldsdst), "s"(sbase));
+}
+__device__ __forceinline__ void dma4(uint32_t voff, uint32_t ldsdst, const void *sbase) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(ldsdst), "s"(sbase));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+// workgroup barrier that orders LDS only: the wave's LDS operations are retired, global operations in flight (the
+// LDS-DMA row-steps) stay in flight across it (__syncthreads() would wait for them)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 24 bytes at an 8-byte aligned LDS address; loads and their wait in ONE statement (the compiler's waitcnt pass does
+// not see LDS operations inside asm)
+__device__ __forceinline__ Row24 ring_read24(uint32_t addr) {
+    unsigned long long r0, r1, r2;
+    asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                 : "v"(addr));
+    Row24 v;
+    v.d[0] = (uint32_t)r0; v.d[1] = (uint32_t)(r0 >> 32);
+    v.d[2] = (uint32_t)r1; v.d[3] = (uint32_t)(r1 >> 32);
+    v.d[4] = (uint32_t)r2; v.d[5] = (uint32_t)(r2 >> 32);
+    return v;
+}
+
+// column pass + quantise + stage in LDS (as block_to_stage's second half); returns the DC level
+template <bool STAGE8>
+__device__ __forceinline__ int columns_to_stage(const float rows[64], const M1V_CONST_AS float *rq_t, uint32_t &lds_addr) {
+    int dc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float c[8];
+        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
+                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = quant(c[u], rq_t[i * 8 + u]);
+            const int p = scan_pos(u * 8 + i);
+            if (p == 0) dc = q;
+            if (STAGE8)
+                asm("ds_write_b8 %0, %1 offset:%2" : "+v"(lds_addr) : "v"(q), "n"(stage_byte8(p)));
+            else
+                asm("ds_write_b16 %0, %1 offset:%2" : "+v"(lds_addr) : "v"(q), "n"(stage_byte16(p)));
+        }
+    }
+    return dc;
+}
+
+#ifndef M1V_TILE_WAVES_PER_EU
+#define M1V_TILE_WAVES_PER_EU 5
+#endif
+
+template <bool STAGE8, int R>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(M1V_TILE_WAVES_PER_EU, M1V_TILE_WAVES_PER_EU)))
+void k_encode_tiles(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Geometry &g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool chroma = wave == 2; // wave-uniform
+    constexpr int kStride = STAGE8 ? kStageStride8 : kStageStride16;
+
+    uint32_t *vlc = lds + kTileVlc, *cnt = lds + kTileCnt, *G = lds + kTileG, *segtab = lds + kTileSegTab, *misc = lds + kTileMisc;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t region_off = (uint32_t)kTileFixedWords * 4u + (uint32_t)wave * a.luma_region; // bytes from lds
+    uint32_t *image = lds + kTileFixedWords + (2u * a.luma_region + a.chroma_region) / 4u;
+
+    int frame, tile;
+    frame_strip_of(blockIdx.x, a.n_frames, a.tiles_per_frame, frame, tile);
+    const int tr = tile / a.tile_cols, tc = tile - tr * a.tile_cols;
+    const int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
+    const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+    const unsigned long long tile_index = (unsigned long long)frame * a.tiles_per_frame + tile;
+
+    // ---- which block this lane owns ----
+    int j, m, blk; // strip and macroblock row inside the tile, block inside the macroblock (Y0 Y1 Y2 Y3 Cb Cr)
+    if (!chroma) {
+        m = 2 * wave + (lane >> 5);
+        blk = ((lane >> 4) & 1) * 2 + (lane & 1);
+        j = (lane >> 1) & 7;
+    } else {
+        m = (lane >> 3) & 3;
+        blk = 4 + (lane >> 5);
+        j = lane & 7;
+    }
+    const int strips_here = min(kTileStrips, g.n_strips - s0); // >= 1
+    const bool valid = j < strips_here && m0 + m < g.n_mbrows;
+    const int e = j * kTileSegBlocks + m * 6 + blk; // position in the tile's emission order (strip, macroblock, block)
+
+    // ---- the lane's share of the wave's DMA: 16 bytes of every row-step.  Pieces that lie outside the picture region
+    //      (last tile column / row) re-read bytes of the last strip / macroblock row; their lanes are not `valid`. ----
+    const uint32_t step_bytes = chroma ? kChromaStep : kLumaStep;
+    const uint32_t pitch = chroma ? (uint32_t)g.half_w * 3u : (uint32_t)g.W * 3u; // bytes from row i to row i + 1 of a block
+    uint32_t voff_a, voff_b = 0; // byte offsets from the frame base of this lane's 16 bytes of row 0 (first / second instruction)
+    if (!chroma) {
+        const uint32_t vw = (uint32_t)strips_here * 48u;
+        auto off = [&](uint32_t L) { // L-th 16-byte unit of the 1536-byte row-step: piece = picture row, `within` inside its 384 bytes
+            const uint32_t piece = L / 24u, within = min((L - piece * 24u) * 16u, vw - 16u);
+            const uint32_t mb = (uint32_t)min(m0 + 2 * wave + (int)(piece >> 1), g.n_mbrows - 1);
+            return ((mb * 16u + (piece & 1u) * 8u) * (uint32_t)g.W + (uint32_t)s0 * 16u) * 3u + within;
+        };
+        voff_a = off((uint32_t)lane);
+        voff_b = off(64u + (uint32_t)(lane & 31));
+    } else {
+        const uint32_t vw = (uint32_t)strips_here * 24u;
+        // (an odd number of strips ends in the middle of a 16-byte unit: that unit is still fetched whole — up to 8 bytes
+        //  past the tile's last strip, still inside the first quarter of the frame, where all chroma sources lie)
+        const uint32_t L = (uint32_t)min(lane, 47), piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
+        const uint32_t mb = (uint32_t)min(m0 + (int)piece, g.n_mbrows - 1);
+        voff_a = ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
+    }
+    const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
+    auto issue_row = [&](int r) {            // row-step r -> slot r % R
+        const uint8_t *sb = fbase + (size_t)r * pitch;
+        const uint32_t dst = ring + (uint32_t)(r % R) * step_bytes;
+        if (!chroma) {
+            dma16(voff_a, dst, sb);
+            if (lane < 32) dma16(voff_b, dst + 1024u, sb);
+        } else {
+            if (lane < 48) dma16(voff_a, dst, sb);
+        }
+    };
+
+    // ---- everything this wave needs from memory, requested up front: its quarter of the VLC table, R row-steps ----
+    dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kWave) * 4u, a.tab->vlc + wave * kWave);
+#pragma unroll
+    for (int r = 0; r < R; r++) issue_row(r);
+
+    for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
+    // VLC table landed (the oldest request), image cleared: visible to all waves behind this barrier.  The first row-step is
+    // still on its way, so nobody waits here for longer than for its own pixels.
+    if (chroma) wait_vm<R * 1>(); else wait_vm<R * 2>();
+    lds_barrier();
+
+    // ---- pixel stage: rows out of the ring as they land, the freed slot refilled with row i + R ----
+    const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
+    const CompCoefF kf = comp_coef_f(blk < 4 ? 0 : blk - 3);
+    const uint32_t lane_row = ring + (uint32_t)(chroma ? (lane & 31) : lane) * 24u;
+    float rows[64];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int newest = (i - 1 + R < 7) ? (i - 1 + R) : 7; // newest row-step requested so far
+        const int behind = newest - i;                         // row-steps that may still be in flight
+        if (chroma) {
+            if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<1>(); else if (behind == 2) wait_vm<2>();
+            else if (behind == 3) wait_vm<3>(); else if (behind == 4) wait_vm<4>(); else if (behind == 5) wait_vm<5>();
+            else if (behind == 6) wait_vm<6>(); else wait_vm<7>();
+        } else {
+            if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<2>(); else if (behind == 2) wait_vm<4>();
+            else if (behind == 3) wait_vm<6>(); else if (behind == 4) wait_vm<8>(); else if (behind == 5) wait_vm<10>();
+            else if (behind == 6) wait_vm<12>(); else wait_vm<14>();
+        }
+        const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * step_bytes);
+        if (i + R < 8) issue_row(i + R);
+        float px[8];
+        convert_row<3, false>(v, kf, px);
+        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
+    }
+    // every row-step has landed and has been read: the ring's bytes now hold the staged levels of the wave's blocks
+    uint32_t *blkp = lds + region_off / 4u + lane * kStride;
+    uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blkp;
+    const int dc = columns_to_stage<STAGE8>(rows, rq_t, lds_addr);
+    const unsigned long long nz = (stage_nonzero_mask<STAGE8>(blkp, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
+
+    // ---- entropy pass 1 (private: own staged levels, shared read-only VLC table) ----
+    auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(blkp, p); };
+    uint32_t hdr = 0, bad = 0;
+    int hlen = 0;
+    BlockBits bb = {0, 0};
+    dc_header(dc, blk < 4, blk, vlc, hdr, hlen);
+    const unsigned long long emit = emit_set(nz);
+    block_bits_pass1<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
+    if (!valid) {
+        bb.tot = 0;
+        bad = 0;
+    }
+    cnt[e] = (uint32_t)bb.tot;
+    lds_barrier();
+
+    // ---- every wave scans the 192 counts (emission order) itself: no second barrier ----
+    const uint32_t c0 = cnt[lane], c1 = cnt[64 + lane], c2 = cnt[128 + lane];
+    const uint32_t i0 = wave_scan_inclusive(c0), i1 = wave_scan_inclusive(c1), i2 = wave_scan_inclusive(c2);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+    G[lane] = i0 - c0;                 // all three waves store the same values: whichever lands last, a wave reads what
+    G[64 + lane] = t0 + i1 - c1;       // it wrote itself
+    G[128 + lane] = t0 + t1 + i2 - c2;
+    if (lane == 63) G[192] = t0 + t1 + i2;
+    // segment table: lanes 0..7 = the tile's strips
+    const uint32_t slice_bits = tr == 0 ? 38u : 0u; // the strip starts in this tile: slice header in front (mpeg1_blk.c:12-16)
+    const uint32_t gs = G[min(lane, 8) * kTileSegBlocks];
+    const uint32_t gs_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gs, 0x101, 0xf, 0xf, true); // row_shl:1
+    const uint32_t seg_bits = lane < strips_here ? slice_bits + (gs_next - gs) : 0u;
+    const uint32_t seg_words = lane < 8 ? (seg_bits + 31u) >> 5 : 0u;
+    const uint32_t seg_incl = row_scan_inclusive(seg_words);
+    const uint32_t end_words = (uint32_t)__builtin_amdgcn_readlane((int)seg_incl, 7);
+    if (lane < 8) {
+        segtab[2 * lane] = gs;
+        segtab[2 * lane + 1] = seg_incl - seg_words;
+    }
+    const uint32_t my_gs = segtab[2 * j], my_base = segtab[2 * j + 1];
+    const uint32_t off = my_base * 32u + slice_bits + (G[e] - my_gs);
+
+    auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
+    uint2 *seg_out = a.seg + ((unsigned long long)frame * g.n_strips + (unsigned)(s0 + lane)) * a.tile_rows + tr; // lanes < strips_here
+    auto slice_headers = [&](uint32_t *img, bool swapped) { // wave 0, lanes < strips_here
+        if (tr == 0) {
+            const uint32_t h0 = slice_word0(s0 + lane), h1 = kSliceWord1, w = seg_incl - seg_words;
+            atomicOr(&img[w], swapped ? __builtin_bswap32(h0) : h0);
+            atomicOr(&img[w + 1], swapped ? __builtin_bswap32(h1) : h1);
+        }
+    };
+
+    // ---- image too large for LDS (rare): global atomics in a worst-case slot of the overflow arena ----
+    if (end_words + 2 > (uint32_t)a.lds_words) {
+        if (tid == 0) misc[0] = atomicAdd(a.arena_next, 1u);
+        __syncthreads();
+        const uint32_t got = misc[0];
+        if (got >= a.arena_slots) { // arena exhausted: the caller re-encodes after m1v_reserve_scratch
+            if (tid == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_SCRATCH);
+            if (wave == 0 && lane < strips_here) *seg_out = make_uint2(0u, 0u);
+            return;
+        }
+        const unsigned long long where = a.arena_off + (unsigned long long)got * a.run_cap;
+        uint32_t *big = reinterpret_cast<uint32_t *>(a.scratch + where);
+        for (uint32_t i = tid; i < (a.run_cap >> 2); i += kTileThreads) big[i] = 0;
+        __syncthreads();
+        if (wave == 0 && lane < strips_here) {
+            slice_headers(big, true);
+            *seg_out = make_uint2(seg_bits, (uint32_t)(where >> 2) + (seg_incl - seg_words));
+        }
+        if (valid) put_block<true>(big, off, bb, walk);
+        if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+        return;
+    }
+
+    // ---- common path: OR the bits into the LDS image, store it once to the tile's compact slot ----
+    if (wave == 0 && lane < strips_here) {
+        slice_headers(image, false);
+        *seg_out = make_uint2(seg_bits, (uint32_t)((tile_index * a.slot_bytes) >> 2) + (seg_incl - seg_words));
+    }
+    if (valid) put_block<false>(image, off, bb, walk);
+    lds_barrier();
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + tile_index * a.slot_bytes);
+    for (uint32_t i = tid; i < end_words; i += kTileThreads) slot32[i] = __builtin_bswap32(image[i]);
+    if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+}
+
+// ---- layout and gather for tiles: a strip is the concatenation of its tile_rows segments ---------------------------
+struct TileGeom {
+    int n_frames, n_strips, tile_rows;
+};
+
+// One workgroup per frame: bit prefix of every strip's segments, strip byte counts, exclusive scan of the strips.
+__global__ __launch_bounds__(256) void k_tile_layout(TileGeom d, const uint2 *seg, uint32_t *seg_pre, uint32_t *strip_bytes,
+                                                     uint32_t *strip_off, unsigned long long *frame_size) {
+    __shared__ uint32_t ws[32];
+    const int f = blockIdx.x;
+    uint32_t run_total = 0;
+    for (int base = 0; base < d.n_strips; base += 256) {
+        const int s = base + threadIdx.x;
+        uint32_t nbytes = 0;
+        if (s < d.n_strips) {
+            const size_t i = (size_t)f * d.n_strips + s;
+            uint32_t bits = 0;
+            for (int t = 0; t < d.tile_rows; t++) {
+                seg_pre[i * d.tile_rows + t] = bits;
+                bits += seg[i * d.tile_rows + t].x;
+            }
+            nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+            strip_bytes[i] = nbytes;
+        }
+        uint32_t tot;
+        const uint32_t off = block_scan_exclusive(nbytes, ws, 256, tot);
+        if (s < d.n_strips) strip_off[(size_t)f * d.n_strips + s] = run_total + off;
+        run_total += tot;
+    }
+    if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
+}
+
+struct TileGatherArgs {
+    TileGeom d;
+    const uint8_t *scratch;
+    const uint2 *seg;
+    const uint32_t *seg_pre, *strip_bytes, *strip_off;
+    const unsigned long long *frame_size, *frame_off;
+    const Tables *tab;
+    uint8_t *out;
+    unsigned long long out_cap;
+    uint32_t *status;
+    int first_index;
+};
+
+constexpr int kTileGatherThreads = 64;
+__global__ __launch_bounds__(kTileGatherThreads) void k_gather_tiles(TileGatherArgs a) {
+    extern __shared__ uint32_t gl[]; // [tile_rows + 1] bit prefix, [tile_rows] bits, [tile_rows] source word offset
+    const TileGeom &d = a.d;
+    const int s = blockIdx.x, f = blockIdx.y, T = d.tile_rows;
+    const unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
+    if (fo + fs > a.out_cap) {
+        if (threadIdx.x == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
+        return;
+    }
+    const size_t idx = (size_t)f * d.n_strips + s;
+    uint32_t *pre = gl, *bits = gl + T + 1, *src = gl + 2 * T + 1;
+    for (int t = threadIdx.x; t < T; t += kTileGatherThreads) {
+        const uint2 sg = a.seg[idx * T + t];
+        pre[t] = a.seg_pre[idx * T + t];
+        bits[t] = sg.x;
+        src[t] = sg.y;
+    }
+    const uint32_t n = a.strip_bytes[idx];
+    if (threadIdx.x == 0) pre[T] = 0xffffffffu;
+    __syncthreads();
+    uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
+    const uint32_t nwords = (n + 3) >> 2;
+    for (uint32_t w = threadIdx.x; w < nwords; w += kTileGatherThreads) {
+        const uint32_t lo_bit = 32u * w;
+        int k = 0; // last segment that starts at or before lo_bit
+        for (int step = 1 << (31 - __builtin_clz((unsigned)T | 1u)); step > 0; step >>= 1)
+            if (k + step < T && pre[k + step] <= lo_bit) k += step;
+        uint32_t val = 0;
+        for (; k < T && pre[k] < lo_bit + 32u; k++) val |= strip_bits_from(a.scratch + (size_t)src[k] * 4, pre[k], bits[k], lo_bit);
+        const uint32_t b0 = 4u * w;
+        uint8_t *o = dst + b0;
+        if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
+            *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
+        } else {
+            for (uint32_t q = 0; q < 4u && b0 + q < n; q++) o[q] = (uint8_t)(val >> (24u - 8u * q));
+        }
+    }
+    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
+}

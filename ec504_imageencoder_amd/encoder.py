@@ -233,6 +233,16 @@ class Mpeg1Encoder:
         if rc != _ffi.OK:
             raise EncoderError(rc, "m1v_debug_set_input_mode")
 
+    def debug_set_path(self, path):
+        """Test hook: which encode kernel serves the batches: -1 by geometry, 0 runs, 1 tiles (see mpeg1_hip.h)."""
+        rc = _ffi.lib().m1v_debug_set_path(self._h, {"auto": -1, "runs": 0, "tiles": 1}.get(path, path))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_debug_set_path")
+
+    @property
+    def path(self):
+        return "tiles" if _ffi.lib().m1v_path_in_use(self._h) == 1 else "runs"
+
     def debug_set_lds_words(self, words):
         _ffi.lib().m1v_debug_set_lds_words(self._h, int(words))
 

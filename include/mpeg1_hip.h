@@ -158,7 +158,7 @@ int m1v_synth_device(uint8_t *d_rgb, size_t bytes_per_frame, int n_frames, uint6
                      uint64_t first_frame_index, void *stream);
 
 /* Kernel timing by HIP events recorded on the launch stream around the dominant kernel
- * (k_encode_dense / k_encode_strips).  enable!=0 starts collecting; m1v_profile_read synchronises the recorded events
+ * (k_encode_tiles; k_encode_dense / k_encode_strips on the run path).  enable!=0 starts collecting; m1v_profile_read synchronises the recorded events
  * and returns launches/total milliseconds since the last read. */
 int m1v_profile_enable(m1v_encoder *enc, int enable);
 int m1v_profile_read(m1v_encoder *enc, int *launches, double *total_ms);
@@ -168,12 +168,19 @@ int m1v_profile_read_times(m1v_encoder *enc, float *ms, int cap, int *launches);
 /* Test hook: capacity in 32-bit words of the per-strip LDS bit buffer (0 = default).  A tiny value
  * forces the global-memory fallback path so that tests can cover it. */
 int m1v_debug_set_lds_words(m1v_encoder *enc, int words);
-/* Test hook: force how the dense encode kernel loads its pixels: -1 = automatic (by width, channel count and pointer
- * alignment), 0 = byte loads (valid everywhere), 2 = 28-byte loads + funnel shift (3 channels, 4-byte aligned buffer).
- * A mode that is not valid for the buffer at hand is ignored.  Lets tests compare the load paths on one buffer. */
+/* Two encode kernels serve the path.  TILES (default for 3-channel pictures of any width and alignment): a workgroup
+ * owns 8 adjacent strips x 4 macroblock rows and brings the pixels in as whole 128-byte lines by LDS-DMA.  RUNS (4-channel
+ * pictures): a workgroup owns 256 consecutive blocks of the stream, every lane loads its own 24-byte block rows.  Both
+ * produce the same bytes.  Test hook: -1 = by geometry, 0 = runs, 1 = tiles (3 channels only). */
+int m1v_debug_set_path(m1v_encoder *enc, int path);
+int m1v_path_in_use(const m1v_encoder *enc); /* 1 = tiles, 0 = runs */
+/* Test hook: force how the RUN kernel loads its pixels (forcing a mode selects the run path): -1 = automatic (by width,
+ * channel count and pointer alignment), 0 = byte loads (valid everywhere), 2 = 28-byte loads + funnel shift (3 channels,
+ * 4-byte aligned buffer).  A mode that is not valid for the buffer at hand is ignored.  Lets tests compare the load paths
+ * on one buffer. */
 int m1v_debug_set_input_mode(m1v_encoder *enc, int mode);
-/* Tuning/test hook: blocks per workgroup of the dense encode kernel (multiple of 64, 64..384, not more than
- * the blocks of one strip; 0 = default). */
+/* Tuning/test hook: blocks per workgroup of the RUN kernel (multiple of 64, 64..384, not more than the blocks of one
+ * strip; 0 = default).  Forcing a run length selects the run path unless m1v_debug_set_path says tiles. */
 int m1v_debug_set_dense_threads(m1v_encoder *enc, int threads);
 
 #ifdef __cplusplus

@@ -85,9 +85,15 @@ def run(budget=120.0, seed=2026, big=False, max_cases=None, max_pixels=1920 * 12
             enc.set_pipelined(True)
         if rng.random() < 0.25:
             enc.debug_set_input_mode(int(rng.choice([0, 2])))
-        desc = f"{W}x{H}x{C} {mode} qf{qf} n{n} {kind} first{first}"
+        if C == 3 and rng.random() < 0.5:
+            enc.debug_set_path("tiles")     # wins over a forced run length; a forced input mode still selects the run kernel
+        shift = int(rng.choice([0, 0, 1, 2, 3, 4, 8]))          # where the frames start inside their allocation
+        flat = torch.empty(rgb.size + 16, dtype=torch.uint8, device="cuda")
+        dev = flat[shift:shift + rgb.size].view(rgb.shape)
+        dev.copy_(torch.from_numpy(rgb))
+        desc = f"{W}x{H}x{C} {mode} qf{qf} n{n} {kind} first{first} path={enc.path} shift{shift}"
         try:
-            got, sizes = enc.encode_to_bytes(torch.from_numpy(rgb).cuda(), first)
+            got, sizes = enc.encode_to_bytes(dev, first)
             if expect_error:
                 fails.append("MISSED ERROR " + desc)
             elif got != want or sizes != [int(x) for x in wsizes]:

@@ -284,6 +284,39 @@ def test_extreme_levels_at_the_narrow_staging_boundary(torch_cuda, orc, qf):
     enc.close()
 
 
+@pytest.mark.parametrize("W,H,mode,qf,n,shift", [
+    (1920, 1080, "full", 12, 2, 0),    # the benchmark geometry: 15 x 17 tiles, last tile row 3 macroblock rows
+    (352, 288, "full", 12, 3, 0),      # 22 strips: last tile column 6 strips wide; 18 macroblock rows = 4.5 tile rows
+    (352, 288, "strict", 50, 2, 0),    # the reference's 96 x 144 corner: one tile column of 6 strips, 2.25 tile rows
+    (101, 49, "full", 12, 2, 0),       # odd width: rows start at every byte phase
+    (366, 150, "full", 75, 2, 1),      # odd width AND the buffer itself starts off a 4-byte boundary
+    (1366, 768, "full", 90, 1, 3),     # wide staging (int16 levels), unaligned buffer
+    (16, 16, "full", 12, 3, 0),        # one macroblock
+    (4112, 144, "full", 25, 1, 2),     # 257 strips: strip byte wraps (uint8), 33 tile columns
+    (640, 2304, "full", 100, 1, 0),    # 144 macroblock rows = 36 tile rows, divisor 1 everywhere
+])
+def test_tile_and_run_paths_agree_with_the_oracle(torch_cuda, orc, W, H, mode, qf, n, shift):
+    """The two encode kernels (tiles: LDS-DMA of 8-strip x 4-macroblock-row tiles; runs: a lane loads its own block rows)
+    give the oracle's bytes on the same buffer, also when the buffer starts at an odd address (`shift` bytes into an
+    allocation)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(W * 31 + H + qf)
+    rgb = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    rgb[:, : H // 2] = (rgb[:, : H // 2] // 32) * 32          # upper half compressible: short and long blocks in one strip
+    want, wsizes = orc.encode_frames(rgb, n, W, H, 250, qf, _omode(orc, mode), threads=8)
+    flat = torch.empty(rgb.size + 16, dtype=torch.uint8, device="cuda")
+    dev = flat[shift:shift + rgb.size].view(n, H, W, 3)
+    dev.copy_(torch.from_numpy(rgb))
+    for path in ("tiles", "runs"):
+        enc = _enc(W, H, qf, mode, max_frames=n)
+        enc.debug_set_path(path)
+        assert enc.path == path
+        got, sizes = enc.encode_to_bytes(dev, first_frame_index=250)
+        assert sizes == [int(x) for x in wsizes], (path, sizes[:4], [int(x) for x in wsizes[:4]])
+        assert got == want, path
+        enc.close()
+
+
 @pytest.mark.parametrize("threads", [64, 128, 192, 256, 320, 384])
 def test_dense_run_lengths(torch_cuda, orc, threads):
     """Every supported run length of the dense kernel gives the same bytes (segment stitching at all phases)."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of library variants (build/libencoder_<name>.so): interleaved rounds on ONE device,
-kernel time of k_encode_strips from the library's HIP events.  usage: ab.py name1 name2 ... [--w W --h H --n N]"""
+kernel time of the encode kernel from the library's HIP events.  usage: ab.py name1 name2 ... [--w W --h H --n N]
+name = variant[:T[:W[:path]]], e.g. base:::runs base:::tiles"""
 import argparse
 import ctypes as C
 import os
@@ -23,8 +24,9 @@ import torch
 vp = C.c_void_p
 libs = {}
 for nm in a.names:
-    parts = nm.split(":")                      # "name[:T[:W]]" = library variant, dense run length T, LDS image words W
+    parts = nm.split(":")                      # "name[:T[:W[:path]]]" = library variant, run length T, LDS image words W, path (runs | tiles)
     lib_nm, dense_t, lds_w = parts[0], (parts[1] if len(parts) > 1 else ""), (parts[2] if len(parts) > 2 else "")
+    which = parts[3] if len(parts) > 3 else ""
     path = os.path.join(ROOT, "ec504_imageencoder_amd", "libencoder.so") if lib_nm == "base" else os.path.join(ROOT, "build", f"libencoder_{lib_nm}.so")
     L = C.CDLL(path)
     L.m1v_create.argtypes = [C.POINTER(vp)] + [C.c_int] * 7
@@ -42,6 +44,9 @@ for nm in a.names:
     if lds_w:
         L.m1v_debug_set_lds_words.argtypes = [vp, C.c_int]
         L.m1v_debug_set_lds_words(h, int(lds_w))
+    if which:
+        L.m1v_debug_set_path.argtypes = [vp, C.c_int]
+        assert L.m1v_debug_set_path(h, {"runs": 0, "tiles": 1}[which]) == 0, L.m1v_last_error()
     libs[nm] = (L, h)
 rgb = torch.empty((a.n, a.h, a.w, 3), dtype=torch.uint8, device="cuda")
 L0, h0 = libs[a.names[0]]
