@@ -294,12 +294,16 @@ def main():
                 h_outs[b].copy_(outs[b][:per_rank], non_blocking=True)
                 torch.cuda.current_stream().synchronize()
             pipe = StepPipeline(encode, h_outs, h_metas, world, rank, transport=args.gather, host_buffer=host_buf,
-                                gather_capacity=world * per_rank)
+                                gather_capacity=world * per_rank, retry=lambda b: (enc.reserve_scratch(True), encode(b)))
         else:
             def encode(b):
                 enc.encode(rgb, first, out=outs[b], sizes=sizes, meta=metas[b])
+            def retry(b):      # a batch ran out of overflow scratch: reserve the worst case, encode the same frames again
+                enc.reserve_scratch(True)
+                encode(b)
+                torch.cuda.current_stream().synchronize()
             pipe = StepPipeline(encode, outs, metas, world, rank, transport=args.gather, host_buffer=host_buf,
-                                gather_capacity=world * per_rank)
+                                gather_capacity=world * per_rank, retry=retry)
 
     def step():
         nonlocal step_no

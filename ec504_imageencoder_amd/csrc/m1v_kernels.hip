@@ -1866,9 +1866,9 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
     if (err == hipSuccess) err = hipMemcpy(e->d_tab, t, sizeof(Tables), hipMemcpyHostToDevice);
     delete t;
-#ifdef M1V_STAMPS
-    if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 16 * 8);
-    if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 16 * 8);
+#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS)
+    if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 32 * 8);
+    if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 32 * 8);
 #endif
     if (err == hipSuccess) err = configure_path(e) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
     const void *kernels[] = {(const void *)&k_encode_dense<1, true>, (const void *)&k_encode_dense<1, false>,
@@ -2010,13 +2010,13 @@ int m1v_debug_set_path(m1v_encoder *e, int path) {
 
 int m1v_path_in_use(const m1v_encoder *e) { return e ? (e->tiles ? 1 : 0) : -1; }
 
-#ifdef M1V_STAMPS
-// diagnostic build only: read and clear the per-phase cycle sums
-int m1v_debug_read_stamps(m1v_encoder *e, unsigned long long out[16]) {
+#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS)
+// diagnostic builds only: read and clear the per-phase cycle sums
+int m1v_debug_read_stamps(m1v_encoder *e, unsigned long long out[32]) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, e->d_stamps, 16 * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(e->d_stamps, 0, 16 * 8));
+    HIP_TRY(hipMemcpy(out, e->d_stamps, 32 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(e->d_stamps, 0, 32 * 8));
     return M1V_OK;
 }
 #endif
@@ -2129,6 +2129,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.run_cap = e->run_cap;
         a.luma_region = e->luma_region;
         a.chroma_region = e->chroma_region;
+        a.stamps = e->d_stamps;
         const size_t lds = (size_t)kTileFixedWords * 4 + 2 * (size_t)a.luma_region + a.chroma_region + (size_t)a.lds_words * 4;
         if (lds > 160 * 1024) return fail(M1V_E_ARG, "LDS budget exceeded%s");
         dim3 grid((unsigned)((size_t)n_frames * e->tiles_per_frame)), block((unsigned)kTileThreads);

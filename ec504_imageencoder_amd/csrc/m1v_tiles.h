@@ -48,6 +48,7 @@ struct TileArgs {
     int lds_words;          // capacity of the LDS image of the tile's bits
     uint32_t run_cap;       // bytes of one arena slot: the worst case of a tile
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
+    unsigned long long *stamps; // diagnostic builds only: [0..11] luma waves, [12..23] the chroma wave
 };
 
 #define M1V_CONST_AS __attribute__((address_space(4)))
@@ -88,15 +89,44 @@ __device__ __forceinline__ Row24 ring_read24(uint32_t addr) {
     return v;
 }
 
+// The 64 outputs of the row pass, held until the column pass.  Columns KEEP..7 are stored as f16 PAIRS: every row output
+// except column 0 (the plain sum, which also carries the pixel bias) is an integer of magnitude <= 1020
+// (fdct_f32.h; tools/fdct_f32_proof.cpp checks the bound), which f16 holds exactly, so packing (v_cvt_pkrtz_f16_f32) and
+// unpacking (v_cvt_f32_f16) lose nothing.  24 registers instead of 64 for KEEP = 2: the pixel stage then fits 72 VGPRs
+// (7 waves per SIMD) where the unpacked form needs 96 (5).
+typedef __fp16 m1v_h2 __attribute__((ext_vector_type(2)));
+template <int KEEP>
+struct RowStore {
+    static_assert(KEEP >= 1 && KEEP <= 8 && (8 - KEEP) % 2 == 0, "column 0 stays f32; pairs of columns are packed");
+    float f[8][KEEP];
+    m1v_h2 h[8][(8 - KEEP) / 2 + 1];
+    __device__ __forceinline__ void put(int r, const float out[8]) {
+#pragma unroll
+        for (int c = 0; c < KEEP; c++) f[r][c] = out[c];
+#pragma unroll
+        for (int c = KEEP; c < 8; c += 2) {
+            m1v_h2 v = __builtin_amdgcn_cvt_pkrtz(out[c], out[c + 1]);
+            // pinned here (volatile statements keep their order, and the next row's LDS read is one): left to itself the
+            // scheduler sinks all packing behind the last row and the unpacked values spill
+            asm volatile("" : "+v"(v));
+            h[r][(c - KEEP) / 2] = v;
+        }
+    }
+    __device__ __forceinline__ float get(int r, int c) const {
+        if (c < KEEP) return f[r][c];
+        return (float)h[r][(c - KEEP) / 2][(c - KEEP) & 1];
+    }
+};
+
 // column pass + quantise + stage in LDS (as block_to_stage's second half); returns the DC level
-template <bool STAGE8>
-__device__ __forceinline__ int columns_to_stage(const float rows[64], const M1V_CONST_AS float *rq_t, uint32_t &lds_addr) {
+template <bool STAGE8, int KEEP>
+__device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, const M1V_CONST_AS float *rq_t, uint32_t &lds_addr) {
     int dc = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float c[8];
-        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+        m1vf::fdct_col_f<float>(rows.get(0, i), rows.get(1, i), rows.get(2, i), rows.get(3, i), rows.get(4, i), rows.get(5, i),
+                                rows.get(6, i), rows.get(7, i), c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = quant(c[u], rq_t[i * 8 + u]);
@@ -111,8 +141,41 @@ __device__ __forceinline__ int columns_to_stage(const float rows[64], const M1V_
     return dc;
 }
 
+#ifndef M1V_TILE_KEEP
+#define M1V_TILE_KEEP 2
+#endif
+// Diagnostic build only (-DM1V_TILE_STAMPS, tools/tile_stamps.py): cycles a wave spends in each phase, kept in scalar
+// registers and added to TileArgs::stamps once at the end (a global atomic inside the row loop would join the vmcnt queue).
+#ifdef M1V_TILE_STAMPS
+#define TSTAMP(ph)                                                                                 \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
+        asm volatile("s_waitcnt lgkmcnt(0)");                                                      \
+        tstamp_[ph] += now_ - tstamp_t_;                                                           \
+        tstamp_t_ = now_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define TSTAMP_INIT()                                                                              \
+    unsigned long long tstamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                          \
+    unsigned long long tstamp_t_ = __builtin_amdgcn_s_memtime();                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)")
+#define TSTAMP_FLUSH()                                                                             \
+    do {                                                                                           \
+        if (lane == 0)                                                                             \
+            for (int ph_ = 0; ph_ < 12; ph_++) atomicAdd(&a.stamps[ph_ + (chroma ? 12 : 0)], tstamp_[ph_]); \
+    } while (0)
+#else
+#define TSTAMP(ph) do { } while (0)
+#define TSTAMP_INIT() do { } while (0)
+#define TSTAMP_FLUSH() do { } while (0)
+#endif
+
+#ifndef M1V_TILE_LEAN
+#define M1V_TILE_LEAN false
+#endif
 #ifndef M1V_TILE_WAVES_PER_EU
-#define M1V_TILE_WAVES_PER_EU 5
+#define M1V_TILE_WAVES_PER_EU 7
 #endif
 
 template <bool STAGE8, int R>
@@ -138,20 +201,25 @@ void k_encode_tiles(TileArgs a) {
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
     const unsigned long long tile_index = (unsigned long long)frame * a.tiles_per_frame + tile;
 
-    // ---- which block this lane owns ----
-    int j, m, blk; // strip and macroblock row inside the tile, block inside the macroblock (Y0 Y1 Y2 Y3 Cb Cr)
-    if (!chroma) {
-        m = 2 * wave + (lane >> 5);
-        blk = ((lane >> 4) & 1) * 2 + (lane & 1);
-        j = (lane >> 1) & 7;
-    } else {
-        m = (lane >> 3) & 3;
-        blk = 4 + (lane >> 5);
-        j = lane & 7;
-    }
+    // ---- which block a lane owns: strip j and macroblock row m inside the tile, block inside the macroblock (Y0 Y1 Y2 Y3 Cb Cr) ----
+    auto owner = [&](int ln, int &j, int &m, int &blk) {
+        if (!chroma) {
+            m = 2 * wave + (ln >> 5);
+            blk = ((ln >> 4) & 1) * 2 + (ln & 1);
+            j = (ln >> 1) & 7;
+        } else {
+            m = (ln >> 3) & 3;
+            blk = 4 + (ln >> 5);
+            j = ln & 7;
+        }
+    };
     const int strips_here = min(kTileStrips, g.n_strips - s0); // >= 1
-    const bool valid = j < strips_here && m0 + m < g.n_mbrows;
-    const int e = j * kTileSegBlocks + m * 6 + blk; // position in the tile's emission order (strip, macroblock, block)
+    int comp;
+    {
+        int j_, m_, blk_;
+        owner(lane, j_, m_, blk_);
+        comp = blk_ < 4 ? 0 : blk_ - 3;
+    }
 
     // ---- the lane's share of the wave's DMA: 16 bytes of every row-step.  Pieces that lie outside the picture region
     //      (last tile column / row) re-read bytes of the last strip / macroblock row; their lanes are not `valid`. ----
@@ -188,6 +256,7 @@ void k_encode_tiles(TileArgs a) {
     };
 
     // ---- everything this wave needs from memory, requested up front: its quarter of the VLC table, R row-steps ----
+    TSTAMP_INIT();
     dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kWave) * 4u, a.tab->vlc + wave * kWave);
 #pragma unroll
     for (int r = 0; r < R; r++) issue_row(r);
@@ -195,14 +264,16 @@ void k_encode_tiles(TileArgs a) {
     for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
     // VLC table landed (the oldest request), image cleared: visible to all waves behind this barrier.  The first row-step is
     // still on its way, so nobody waits here for longer than for its own pixels.
+    TSTAMP(0);
     if (chroma) wait_vm<R * 1>(); else wait_vm<R * 2>();
     lds_barrier();
+    TSTAMP(1);
 
     // ---- pixel stage: rows out of the ring as they land, the freed slot refilled with row i + R ----
     const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
-    const CompCoefF kf = comp_coef_f(blk < 4 ? 0 : blk - 3);
+    const CompCoefF kf = comp_coef_f(comp);
     const uint32_t lane_row = ring + (uint32_t)(chroma ? (lane & 31) : lane) * 24u;
-    float rows[64];
+    RowStore<M1V_TILE_KEEP> rows;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         constexpr int dummy = 0;
@@ -221,14 +292,28 @@ void k_encode_tiles(TileArgs a) {
         const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * step_bytes);
         if (i + R < 8) issue_row(i + R);
         float px[8];
-        convert_row<3, false>(v, kf, px);
-        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
+        convert_row<3, M1V_TILE_LEAN>(v, kf, px);
+        float ro[8];
+        m1vf::fdct_row_f<float>(px, ro);
+        rows.put(i, ro);
     }
+    // The lane's place in the tile, derived again behind the pixel stage (from an opaque copy of the lane id: five values
+    // less to carry through the stage, whose register budget decides the waves per SIMD)
+    int j, m, blk;
+    {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        owner(ln, j, m, blk);
+    }
+    const bool valid = j < strips_here && m0 + m < g.n_mbrows;
+    const int e = j * kTileSegBlocks + m * 6 + blk; // position in the tile's emission order (strip, macroblock, block)
     // every row-step has landed and has been read: the ring's bytes now hold the staged levels of the wave's blocks
     uint32_t *blkp = lds + region_off / 4u + lane * kStride;
     uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blkp;
-    const int dc = columns_to_stage<STAGE8>(rows, rq_t, lds_addr);
+    TSTAMP(2);
+    const int dc = columns_to_stage<STAGE8, M1V_TILE_KEEP>(rows, rq_t, lds_addr);
     const unsigned long long nz = (stage_nonzero_mask<STAGE8>(blkp, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
+    TSTAMP(3);
 
     // ---- entropy pass 1 (private: own staged levels, shared read-only VLC table) ----
     auto fetch = [&](int p) -> int { return fetch_level<STAGE8>(blkp, p); };
@@ -243,7 +328,9 @@ void k_encode_tiles(TileArgs a) {
         bad = 0;
     }
     cnt[e] = (uint32_t)bb.tot;
+    TSTAMP(4);
     lds_barrier();
+    TSTAMP(5);
 
     // ---- every wave scans the 192 counts (emission order) itself: no second barrier ----
     const uint32_t c0 = cnt[lane], c1 = cnt[64 + lane], c2 = cnt[128 + lane];
@@ -267,6 +354,7 @@ void k_encode_tiles(TileArgs a) {
     }
     const uint32_t my_gs = segtab[2 * j], my_base = segtab[2 * j + 1];
     const uint32_t off = my_base * 32u + slice_bits + (G[e] - my_gs);
+    TSTAMP(6);
 
     auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
     uint2 *seg_out = a.seg + ((unsigned long long)frame * g.n_strips + (unsigned)(s0 + lane)) * a.tile_rows + tr; // lanes < strips_here
@@ -307,10 +395,14 @@ void k_encode_tiles(TileArgs a) {
         *seg_out = make_uint2(seg_bits, (uint32_t)((tile_index * a.slot_bytes) >> 2) + (seg_incl - seg_words));
     }
     if (valid) put_block<false>(image, off, bb, walk);
+    TSTAMP(7);
     lds_barrier();
+    TSTAMP(8);
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + tile_index * a.slot_bytes);
     for (uint32_t i = tid; i < end_words; i += kTileThreads) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+    TSTAMP(9);
+    TSTAMP_FLUSH();
 }
 
 // ---- layout and gather for tiles: a strip is the concatenation of its tile_rows segments ---------------------------

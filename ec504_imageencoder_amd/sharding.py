@@ -154,15 +154,23 @@ class StepPipeline:
     step()   encode of the next step into buffer b; the exchange of the previous step runs behind it on the side stream
     drain()  exchanges whatever is still pending
     fence()  drain + wait for the device; afterwards `result()` is rank 0's gathered stream of the LAST step
+
+    The status word travels with the byte count: a batch whose status is not zero has undefined output
+    (include/mpeg1_hip.h), so nothing of it is shipped.  M1V_STATUS_SCRATCH on any rank: the ranks concerned call
+    `retry(b)` — which must re-encode buffer b's batch with the worst-case scratch reserved
+    (Mpeg1Encoder.reserve_scratch) and leave its new (total, status) in metas[b] — and the counts are gathered again;
+    any other bit, or a second failure, raises on EVERY rank (all ranks see all status words).
     """
 
+    STATUS_SCRATCH = 4
+
     def __init__(self, encode, outs, metas, world, rank, transport="xgmi", runtime=None, group=None,
-                 host_buffer=None, gather_capacity=None):
+                 host_buffer=None, gather_capacity=None, retry=None):
         import torch
         import torch.distributed as dist
         assert transport in ("xgmi", "host")
         self.torch, self.dist = torch, dist
-        self.encode, self.outs, self.metas = encode, outs, metas
+        self.encode, self.outs, self.metas, self.retry = encode, outs, metas, retry
         self.world, self.rank, self.group, self.transport = world, rank, group, transport
         dev = outs[0].device
         self.rt = runtime if runtime is not None else (_CudaRuntime(dev) if dev.type == "cuda" else _HostRuntime())
@@ -172,26 +180,43 @@ class StepPipeline:
         self.counted = [self.rt.event() for _ in range(nb)]
         self.drained = [None] * nb
         # everything the exchange touches is allocated here, once
-        self.counts_dev = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(nb)]
-        self.counts_host = [self.rt.pinned((world,), torch.int64) for _ in range(nb)]
+        self.counts_dev = [torch.zeros(2 * world, dtype=torch.int64, device=dev) for _ in range(nb)]    # (total, status) per rank
+        self.counts_host = [self.rt.pinned((2 * world,), torch.int64) for _ in range(nb)]
         self.host_buffer = host_buffer                      # transport "host": the node's shared pinned stream
         self.gathered = None                                # transport "xgmi": rank 0's device-side stream
         if transport == "xgmi" and rank == 0:
             cap = gather_capacity if gather_capacity is not None else world * outs[0].numel()
             self.gathered = torch.empty(cap, dtype=torch.uint8, device=dev)
         self.pending, self.step_no = [], 0
-        self.last_counts, self.exchanges = None, 0
+        self.last_counts, self.exchanges, self.retries = None, 0, 0
 
     # ---- one exchange, on the side stream -------------------------------------------------------------
+    def _counts(self, b):
+        """(total, status) of every rank for buffer b, on the host: the step's only host wait (the next encode is
+        already queued on the main stream)."""
+        rt = self.rt
+        self.dist.all_gather_into_tensor(self.counts_dev[b], self.metas[b], group=self.group)
+        self.counts_host[b].copy_(self.counts_dev[b], non_blocking=True)
+        rt.record(self.counted[b], self.side)
+        rt.host_wait(self.counted[b])
+        pairs = [int(x) for x in self.counts_host[b]]
+        return pairs[0::2], [s & 0xFFFFFFFF for s in pairs[1::2]]
+
     def _exchange(self, b):
         rt, dist = self.rt, self.dist
         with rt.on(self.side):
             rt.wait(self.encoded[b], self.side)
-            dist.all_gather_into_tensor(self.counts_dev[b], self.metas[b][0:1], group=self.group)
-            self.counts_host[b].copy_(self.counts_dev[b], non_blocking=True)
-            rt.record(self.counted[b], self.side)
-            rt.host_wait(self.counted[b])       # the step's only host wait; the next encode is already queued
-            counts = [int(x) for x in self.counts_host[b]]
+            counts, status = self._counts(b)
+            if any(status):
+                fatal = [(r, s) for r, s in enumerate(status) if s & ~self.STATUS_SCRATCH]
+                if fatal or self.retry is None:
+                    raise RuntimeError(f"encode status (rank, bits) {fatal or list(enumerate(status))}: the batch's output is undefined")
+                if status[self.rank]:
+                    self.retry(b)               # this rank's batch again, worst-case scratch reserved
+                    self.retries += 1
+                counts, status = self._counts(b)
+                if any(status):
+                    raise RuntimeError(f"encode status {status} after the retry")
             if self.transport == "xgmi":
                 if self.rank == 0:
                     need = sum(counts)

@@ -1,6 +1,7 @@
 """GPU parity tests proper (-m gpu): the HIP path, called through the C-ABI of include/mpeg1_hip.h,
 against the oracle on the same seeded inputs and against the committed golden vectors.
 Bar: bit-exact (integer / byte work; the fp64 colour conversion is truncated to u8)."""
+import functools
 import hashlib
 import struct
 
@@ -57,20 +58,84 @@ def test_colour_conversion_exhaustive_2_24(torch_cuda, orc):
     enc.close()
 
 
-def test_colour_inside_fused_kernel_exhaustive(torch_cuda, orc):
-    """The fused strip kernel converts pixels itself; check its conversion on all 2^24 triples through
-    the DC coefficient path: a flat 8x8 block of colour c has every pixel equal, so compare full
-    coefficient sets of a picture made of flat 16x16 macroblocks with the oracle (8 pictures of 2048^2 / 256)."""
-    torch = torch_cuda
-    W = H = 2048  # 128 x 128 macroblocks = 16384 colours per picture; sample 64 pictures = 2^20 colours
-    enc = _enc(W, H, max_frames=1)
-    rng = np.random.default_rng(11)
-    for _ in range(4):
-        cols = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
-        pic = np.repeat(np.repeat(cols, 16, 0), 16, 1)[None]
-        got = enc.coefficients(torch.from_numpy(pic).cuda()).cpu().numpy().astype(np.int32)[0]
-        assert np.array_equal(got, orc.frame_coefficients(pic[0], W, H, 12, orc.MODE_FULL))
+# ---- colour conversion INSIDE the encode kernels (image_processing.c:104-106) ------------------------------------
+# The encode kernels convert pixels themselves (fp32 fast path + fp64 re-evaluation of ties), with code of their own per
+# input mode.  Pictures of FLAT 8x8 cells at quality 50 pin every converted value: the DC divisor is 8, a flat block of
+# value v has DC 8v + 2, so its level is exactly v and a conversion that is off by one changes the stream.  Cell (r, c)
+# repeats with period W/2 across and H/4 down, which makes the chroma blocks flat too: the chroma block of macroblock
+# (strip s, row mb) is cut from picture rows 4mb..4mb+3, columns [8s, 8s+8) and [W/2+8s, W/2+8s+8) (encoder.h:347-348),
+# and every colour of a picture lies in its top quarter as well, so each one is coded as Y, as Cb and as Cr.
+_CW, _CH = 2048, 1024
+_COLOURS_PER_FRAME = (_CW // 16) * (_CH // 32)
+
+
+def _flat_cell_frames(colours, channels=3, alpha_seed=1):
+    """colours: uint8 [n, 3] -> frames uint8 [ceil(n / 4096), H, W, channels] (the last frame padded with colour 0)."""
+    per = _COLOURS_PER_FRAME
+    nf = (len(colours) + per - 1) // per
+    pad = np.zeros((nf * per, 3), np.uint8)
+    pad[:len(colours)] = colours
+    cells = pad.reshape(nf, _CH // 32, _CW // 16, 3)
+    cells = np.tile(cells, (1, 4, 2, 1))                                   # period H/4 down, W/2 across
+    frames = np.repeat(np.repeat(cells, 8, 1), 8, 2)
+    if channels == 4:
+        alpha = np.random.default_rng(alpha_seed).integers(0, 256, frames.shape[:3] + (1,), dtype=np.uint8)
+        frames = np.concatenate([frames, alpha], -1)
+    return np.ascontiguousarray(frames)
+
+
+@functools.lru_cache(maxsize=1)
+def _tie_colours():
+    """Every (r, g, b) for which at least one of the three formulas is an exact integer or closer than 5e-4 above one:
+    the inputs whose bytes fp64 rounding decides in the reference, and all that take the kernels' fp64 branch."""
+    v = np.arange(1 << 24, dtype=np.int64)
+    r, g, b = v >> 16, (v >> 8) & 255, v & 255
+    y = (299000 * r + 587000 * g + 114000 * b) % 1000000
+    cb = (128000000 - 168736 * r - 331264 * g + 500000 * b) % 1000000
+    cr = (128000000 + 500000 * r - 418688 * g - 81312 * b) % 1000000
+    sel = (y < 500) | (cb < 500) | (cr < 500)
+    return np.stack([r[sel], g[sel], b[sel]], -1).astype(np.uint8)
+
+
+def _check_colours_through(torch, orc, colours, configure, channels=3, chunk=48):
+    enc = _enc(_CW, _CH, 50, "full", channels=channels, max_frames=chunk)
+    configure(enc)
+    per = _COLOURS_PER_FRAME * chunk
+    for lo in range(0, len(colours), per):
+        frames = _flat_cell_frames(colours[lo:lo + per], channels)
+        n = frames.shape[0]
+        want, wsizes = orc.encode_frames(frames, n, _CW, _CH, 0, 50, orc.MODE_FULL, channels=channels, threads=16)
+        got, sizes = enc.encode_to_bytes(torch.from_numpy(frames).cuda(), 0)
+        assert sizes == [int(x) for x in wsizes] and got == want, f"colours {lo}..{lo + per}"
     enc.close()
+
+
+_INPUT_MODES = {
+    "tiles": (3, lambda e: e.debug_set_path("tiles")),                     # LDS-DMA tiles (the default path)
+    "runs-aligned": (3, lambda e: e.debug_set_path("runs")),               # 24-byte row loads
+    "runs-funnel": (3, lambda e: e.debug_set_input_mode(2)),               # 28-byte loads + v_alignbyte
+    "runs-bytes": (3, lambda e: e.debug_set_input_mode(0)),                # byte loads, per-pixel branch
+    "runs-rgba": (4, lambda e: None),                                      # 32-byte rows of 4-channel pixels
+}
+
+
+@pytest.mark.parametrize("mode", list(_INPUT_MODES))
+def test_colour_inside_the_encode_kernels_ties_and_sample(torch_cuda, orc, mode):
+    """All tie / near-tie colours (every input that takes the fp64 branch, ~1 % of 2^24) and 2^20 random colours (2^17
+    for the byte-load mode) through each input mode of the encode kernels, as Y, Cb and Cr each."""
+    channels, configure = _INPUT_MODES[mode]
+    ties = _tie_colours()
+    assert 50000 < len(ties) < 400000
+    rng = np.random.default_rng(2024)
+    sample = rng.integers(0, 256, ((1 << 17) if mode == "runs-bytes" else (1 << 20), 3), dtype=np.uint8)
+    _check_colours_through(torch_cuda, orc, np.concatenate([ties, sample]), configure, channels)
+
+
+def test_colour_inside_the_tile_kernel_exhaustive_2_24(torch_cuda, orc):
+    """Every one of the 2^24 RGB triples through the default encode kernel, coded as Y, Cb and Cr (4096 flat-cell frames)."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    colours = np.stack([v >> 16, (v >> 8) & 255, v & 255], -1).astype(np.uint8)
+    _check_colours_through(torch_cuda, orc, colours, lambda e: None)
 
 
 def test_subsample(torch_cuda, orc):

@@ -12,6 +12,7 @@ for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.cs
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
         if "k_encode_dense" in k: k = "k_encode_dense"
+        elif "k_encode_tiles" in k: k = "k_encode_tiles"
         elif "k_gather" in k: k = "k_gather"
         else: continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -13,6 +13,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--n", type=int, default=300)
+ap.add_argument("--path", default="", help="runs | tiles (default: what the library picks)")
 a = ap.parse_args()
 from ec504_imageencoder_amd import _ffi
 if a.name != "base":
@@ -21,6 +22,8 @@ import torch
 from ec504_imageencoder_amd import Mpeg1Encoder
 
 enc = Mpeg1Encoder(a.w, a.h, 12, "full", max_frames=a.n)
+if a.path:
+    enc.debug_set_path(a.path)
 rgb = enc.synth(a.n)
 for _ in range(a.steps):
     enc.encode(rgb)
