@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--gather", default="xgmi", choices=["xgmi", "host"],
                     help="N>1: how the per-rank bitstreams reach one place.  xgmi = grouped send/recv to rank 0 (RCCL); "
                          "host = every rank copies its blob into its slice of one pinned host buffer shared by the ranks")
+    ap.add_argument("--path", default="auto", choices=["auto", "tiles", "runs"],
+                    help="which encode kernel serves the batches (include/mpeg1_hip.h, m1v_debug_set_path); auto = the library's choice")
     ap.add_argument("--cli", action="store_true",
                     help="instead of the headline run: time the folder-of-JPEGs CLI path end to end (SURVEY 8f.1/8f.2)")
     ap.add_argument("--cli-reference-frames", type=int, default=6)
@@ -253,6 +255,8 @@ def main():
 
     W, H, n, qf, seed = args.width, args.height, args.frames, args.quality, 504
     enc = Mpeg1Encoder(W, H, qf, "full", max_frames=n, device=gpu_index)
+    if args.path != "auto":
+        enc.debug_set_path(args.path)
     first = rank * n  # global frame index of this rank's first frame
     rgb = enc.synth(n, seed=seed, first_frame_index=first, device=dev)
     # two output buffers: for N > 1 the exchange of step k overlaps the encode of step k+1
@@ -375,7 +379,7 @@ def main():
                             ", every rank copies its bitstream into its slice of one pinned host buffer") if distributed else "")},
             # "hbm" is the roofline BASELINE.json prices the path against.  What the time is made of today: vector-ALU issue
             # ("valu": ~0.8 of the kernel time) plus memory latency that 5 waves per SIMD do not hide
-            "roofline": {"bound": "hbm", "kernel": "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(pmc),
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
                          "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,

@@ -220,6 +220,8 @@ __device__ __forceinline__ float component_raw(uint32_t r, uint32_t g, uint32_t 
     return p;
 }
 
+#define M1V_CONST_AS __attribute__((address_space(4)))
+
 struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
@@ -397,6 +399,60 @@ __device__ __forceinline__ void block_bits_pass1(uint32_t hdr, int hlen, bool dc
     tot += 2;
 }
 
+// The same pass, TWO coded coefficients per trip.  What a wave pays for in this loop is not instructions but LDS round
+// trips: a coefficient needs its staged level and its row of the offset index (independent of each other), then the table
+// entry they select — two dependent LDS latencies, and a wave takes as many trips as its longest lane has coefficients
+// (4-6 on noise at quality 12).  The second coefficient's position and run come from the mask alone, so its reads go out
+// with the first one's: half the trips.  A lane without a second coefficient repeats the first (valid addresses) and adds
+// zero bits.
+template <bool NARROW, typename Fetch>
+__device__ __forceinline__ void block_bits_pass1_pairs(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
+                                                       const uint32_t *vlc, Fetch fetch, unsigned long long &acc, int &tot,
+                                                       uint32_t &bad) {
+    acc = hdr;
+    tot = hlen;
+    int prev = dc_nonzero ? 0 : -1;
+    while (emit) {
+        const int pa = __builtin_ctzll(emit);
+        emit &= emit - 1;
+        const bool two = emit != 0;
+        const int pb = two ? __builtin_ctzll(emit) : pa;
+        emit &= emit - 1; // 0 & -1 stays 0
+        const int ra = pa - prev - 2, rb = two ? pb - pa - 2 : ra;
+        prev = pb;
+        // round 1: both levels, both index rows
+        const int la = fetch(pa), lb = fetch(pb);
+        const uint32_t ia = vlc[kVlcRowInfo + min(ra, kAcRows - 1)], ib = vlc[kVlcRowInfo + min(rb, kAcRows - 1)];
+        const uint32_t La = (uint32_t)(la < 0 ? -la : la), Lb = (uint32_t)(lb < 0 ? -lb : lb);
+        const bool ta = ra < kAcRows && La - 1u < (ia >> 8), tb = rb < kAcRows && Lb - 1u < (ib >> 8);
+        // round 2: both entries
+        const uint32_t ea = vlc[kVlcEntries + (ta ? (ia & 0xffu) + La - 1u : 0u)], eb = vlc[kVlcEntries + (tb ? (ib & 0xffu) + Lb - 1u : 0u)];
+        auto finish = [&](int r, int level, uint32_t L, bool in_table, uint32_t e, uint32_t &code, uint32_t &bits) {
+            const uint32_t head = (1u << 6) | ((uint32_t)r & 0x3fu); // "000001" + 6-bit run (vlc.c:346-381)
+            const uint32_t lo = (uint32_t)level & 0xffu;
+            uint32_t esc = (head << 8) | lo, esc_bits = 20;
+            if (!NARROW) {
+                const bool wide = L >= 128u;
+                esc = wide ? (head << 16) | (level < 0 ? 0x8000u : 0u) | lo : esc;
+                esc_bits = wide ? 28 : 20;
+                bad |= (!in_table && L >= 256u) ? 1u : 0u;
+            }
+            code = in_table ? (e & 0xffffu) : esc;
+            bits = in_table ? (e >> 16) : esc_bits;
+        };
+        uint32_t ca, ba, cb, bbits;
+        finish(ra, la, La, ta, ea, ca, ba);
+        finish(rb, lb, Lb, tb, eb, cb, bbits);
+        acc = (acc << ba) | ca;
+        tot += (int)ba;
+        bbits = two ? bbits : 0u;
+        acc = (acc << bbits) | (two ? cb : 0u);
+        tot += (int)bbits;
+    }
+    acc = (acc << 2) | 0x2u; // EOB "10", mpeg1_blk.c:115-117
+    tot += 2;
+}
+
 // The same walk, code word by code word into `sink` (pass 2 of the rare blocks that exceed 64 bits).
 template <bool NARROW, typename Fetch, typename Sink>
 __device__ __forceinline__ void walk_codes(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
@@ -525,6 +581,9 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
 #ifndef M1V_WAVES_PER_EU
 #define M1V_WAVES_PER_EU 5
 #endif
+#ifndef M1V_DENSE_KEEP
+#define M1V_DENSE_KEEP 8 // row-pass outputs of the run kernels stay unpacked (RowStore)
+#endif
 
 // ---- pieces shared by the two encode kernels -----------------------------------------------------
 
@@ -567,21 +626,63 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
     for (int k = 0; k < 6; k++) r.d[k] = __builtin_amdgcn_alignbyte(v.d[k + 1], v.d[k], m);
     return r;
 }
+// Rows kLate24 .. 7 of the aligned 3-channel mode are requested from inside the row loop (once row 0 has been consumed):
+// with the row outputs packed (RowStore) the pixel stage fits 80 VGPRs only if not all 48 raw registers are in flight at
+// its start.  Rows 6 and 7 late measured no slower than all eight up front (profiles/r02_ab_history.txt: 618.6 vs 621.3 us).
+#ifndef M1V_DENSE_LATE
+#define M1V_DENSE_LATE 8
+#endif
+constexpr int kLate24 = M1V_DENSE_LATE;
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < kLate24; i++)
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
 }
 
 // rows: convert + row pass as each row's bytes arrive; columns: column pass + quantise + stage in LDS +
 // non-zero mask, one column at a time (nothing but rows[] stays live).  Returns the DC level.
+// The 64 outputs of the row pass, held until the column pass.  Columns KEEP..7 are stored as f16 PAIRS: every row output
+// except column 0 (the plain sum, which also carries the pixel bias 8 * 256) is an integer of magnitude <= 1020, the sum
+// without its bias one of magnitude <= 2040 (fdct_f32.h; tools/fdct_f32_proof.cpp checks the bounds), and f16 holds every
+// integer up to 2048 exactly, so packing (v_cvt_pkrtz_f16_f32) and unpacking (v_cvt_f32_f16) lose nothing.  KEEP = 0
+// packs all eight columns (the bias comes off column 0 first): 32 registers instead of 64, which is what lets the pixel
+// stage fit 80 VGPRs = 6 waves per SIMD, where the unpacked form needs 96 (5).
+typedef __fp16 m1v_h2 __attribute__((ext_vector_type(2)));
+template <int KEEP>
+struct RowStore {
+    static_assert(KEEP >= 0 && KEEP <= 8 && (8 - KEEP) % 2 == 0, "pairs of columns are packed");
+    static constexpr float kBias0 = KEEP == 0 ? 0.0f : 8.0f * m1vf::kPxBiasF; // what column 0 still carries on top of the sum
+    float f[8][KEEP + 1];
+    m1v_h2 h[8][(8 - KEEP) / 2 + 1];
+    __device__ __forceinline__ void put(int r, const float out[8]) {
+#pragma unroll
+        for (int c = 0; c < KEEP; c++) f[r][c] = out[c];
+#pragma unroll
+        for (int c = KEEP; c < 8; c += 2) {
+            m1v_h2 v = __builtin_amdgcn_cvt_pkrtz(c == 0 ? out[0] - 8.0f * m1vf::kPxBiasF : out[c], out[c + 1]);
+            // pinned here (volatile statements keep their order, and the next row's LDS read is one): left to itself the
+            // scheduler sinks all packing behind the last row and the unpacked values spill
+            asm volatile("" : "+v"(v));
+            h[r][(c - KEEP) / 2] = v;
+        }
+    }
+    __device__ __forceinline__ float get(int r, int c) const {
+        if (c < KEEP) return f[r][c];
+        return (float)h[r][(c - KEEP) / 2][(c - KEEP) & 1];
+    }
+};
+
 template <int FAST, bool STAGE8, typename RowT>
 __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *fbase, const BlockSrc &src,
-                                              const RowT raw[8], const float *rq_t, uint32_t *blk, uint32_t &lds_addr) {
-    float rows[64];
+                                              const RowT raw[8], const float *rq_global, uint32_t *blk, uint32_t &lds_addr) {
+    // constant address space: the table then stays a scalar load behind the volatile statements of RowStore::put
+    const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(rq_global));
+    RowStore<M1V_DENSE_KEEP> rows;
     CompCoefF k = comp_coef_f(src.comp());
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
+    Row24 late24[FAST == 1 && kLate24 < 8 ? 8 - kLate24 : 1];
+    (void)late24;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float px[8];
@@ -592,20 +693,29 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
                     late[r] = *reinterpret_cast<const Row32 *>(fbase + (size_t)((src.first + (uint32_t)(r + 4) * src.stride) * 4u));
             }
             convert_row<4, true>(i < 4 ? raw[i] : late[i - 4], k, px);
+        } else if constexpr (FAST == 1 && kLate24 < 8) {
+            if (i == 1) {
+#pragma unroll
+                for (int r = kLate24; r < 8; r++)
+                    late24[r - kLate24] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u));
+            }
+            convert_row<3, false>(i < kLate24 ? raw[i] : late24[i - kLate24], k, px);
         } else if constexpr (FAST != 0) {
             convert_row<3, FAST == 2>(row_bytes(raw[i], fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u)), k, px);
         } else {
             load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
-        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
+        float ro[8];
+        m1vf::fdct_row_f<float>(px, ro);
+        rows.put(i, ro);
     }
     int dc = 0;
     lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blk;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float c[8];
-        m1vf::fdct_col_f<float>(rows[0 * 8 + i], rows[1 * 8 + i], rows[2 * 8 + i], rows[3 * 8 + i], rows[4 * 8 + i],
-                                rows[5 * 8 + i], rows[6 * 8 + i], rows[7 * 8 + i], c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+        m1vf::fdct_col_f<float>(rows.get(0, i), rows.get(1, i), rows.get(2, i), rows.get(3, i), rows.get(4, i), rows.get(5, i),
+                                rows.get(6, i), rows.get(7, i), c, i == 0 ? RowStore<M1V_DENSE_KEEP>::kBias0 : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = quant(c[u], rq_t[i * 8 + u]);
@@ -1656,7 +1766,7 @@ size_t m1v_file_prolog(uint8_t out[27]) {
 // New buffers are allocated FIRST and swapped in, together with the geometry they belong to, only when every allocation
 // has succeeded: a failed call (the worst-case arena of m1v_reserve_scratch is large) leaves the encoder as it was.
 #ifndef M1V_TILE_RING
-#define M1V_TILE_RING 4
+#define M1V_TILE_RING 2
 #endif
 static int configure_path(m1v_encoder *e) {
     const int dense_T = e->forced_T;
@@ -1679,8 +1789,7 @@ static int configure_path(m1v_encoder *e) {
         plan.tiles_per_frame = plan.tile_cols * plan.tile_rows;
         plan.tile_ring = M1V_TILE_RING;
         const uint32_t stage = (uint32_t)(kWave * (e->narrow ? kStageStride8 : kStageStride16) * 4);
-        plan.luma_region = (std::max<uint32_t>((uint32_t)plan.tile_ring * kLumaStep, stage) + 15u) & ~15u;
-        plan.chroma_region = (std::max<uint32_t>((uint32_t)plan.tile_ring * kChromaStep, stage) + 15u) & ~15u;
+        plan.luma_region = plan.chroma_region = (std::max<uint32_t>((uint32_t)plan.tile_ring * kTileSlot, stage) + 15u) & ~15u;
         // worst case of a tile: 8 word-aligned segments of 24 blocks of <= 886 + 2 bits, 8 slice headers, slack
         plan.run_cap = (uint32_t)(((((size_t)kTileThreads * (kMaxBlockBits + 2) + kTileStrips * (38 + 32) + 64 + 7) / 8) + 32 + 15) & ~(size_t)15);
         // LDS image of the tile's bits (192 blocks: ~115 words at quality 12 on noise), scaled with the quantiser like the

@@ -29,9 +29,10 @@
 constexpr int kTileStrips = 8, kTileMbRows = 4;
 constexpr int kTileThreads = kTileStrips * kTileMbRows * 6; // 192
 constexpr int kTileSegBlocks = kTileMbRows * 6;             // 24 blocks of one strip
-constexpr int kLumaStep = 64 * 24, kChromaStep = 32 * 24;   // bytes of one row-step of a luma / the chroma wave
-// LDS words in front of the per-wave regions: VLC table, bit counts, prefix sums (+ total), segment table, spare
-constexpr int kTileVlc = 0, kTileCnt = 192, kTileG = 384, kTileSegTab = 580, kTileMisc = 596, kTileFixedWords = 600;
+constexpr int kTileSlot = 2048;                             // bytes of one ring slot = one row-step of a wave (two 1-KiB LDS-DMA instructions)
+// LDS words in front of the per-wave regions: one VLC table per wave, bit counts, prefix sums (+ total), segment table, spare
+constexpr int kTileVlc = 0, kTileCnt = 3 * kVlcWords, kTileG = kTileCnt + 192, kTileSegTab = kTileG + 196, kTileMisc = kTileSegTab + 16,
+              kTileFixedWords = kTileMisc + 4; // 984 words
 
 struct TileArgs {
     Geometry g;
@@ -50,8 +51,6 @@ struct TileArgs {
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
     unsigned long long *stamps; // diagnostic builds only: [0..11] luma waves, [12..23] the chroma wave
 };
-
-#define M1V_CONST_AS __attribute__((address_space(4)))
 
 // One LDS-DMA instruction: 16 bytes per active lane from (sbase + voff) to LDS (ldsdst + 16 * lane).  M0 carries the
 // destination and is the compiler's: saved and restored inside the statement (cdna_hip_programming.md, inline asm).
@@ -89,35 +88,6 @@ __device__ __forceinline__ Row24 ring_read24(uint32_t addr) {
     return v;
 }
 
-// The 64 outputs of the row pass, held until the column pass.  Columns KEEP..7 are stored as f16 PAIRS: every row output
-// except column 0 (the plain sum, which also carries the pixel bias) is an integer of magnitude <= 1020
-// (fdct_f32.h; tools/fdct_f32_proof.cpp checks the bound), which f16 holds exactly, so packing (v_cvt_pkrtz_f16_f32) and
-// unpacking (v_cvt_f32_f16) lose nothing.  24 registers instead of 64 for KEEP = 2: the pixel stage then fits 72 VGPRs
-// (7 waves per SIMD) where the unpacked form needs 96 (5).
-typedef __fp16 m1v_h2 __attribute__((ext_vector_type(2)));
-template <int KEEP>
-struct RowStore {
-    static_assert(KEEP >= 1 && KEEP <= 8 && (8 - KEEP) % 2 == 0, "column 0 stays f32; pairs of columns are packed");
-    float f[8][KEEP];
-    m1v_h2 h[8][(8 - KEEP) / 2 + 1];
-    __device__ __forceinline__ void put(int r, const float out[8]) {
-#pragma unroll
-        for (int c = 0; c < KEEP; c++) f[r][c] = out[c];
-#pragma unroll
-        for (int c = KEEP; c < 8; c += 2) {
-            m1v_h2 v = __builtin_amdgcn_cvt_pkrtz(out[c], out[c + 1]);
-            // pinned here (volatile statements keep their order, and the next row's LDS read is one): left to itself the
-            // scheduler sinks all packing behind the last row and the unpacked values spill
-            asm volatile("" : "+v"(v));
-            h[r][(c - KEEP) / 2] = v;
-        }
-    }
-    __device__ __forceinline__ float get(int r, int c) const {
-        if (c < KEEP) return f[r][c];
-        return (float)h[r][(c - KEEP) / 2][(c - KEEP) & 1];
-    }
-};
-
 // column pass + quantise + stage in LDS (as block_to_stage's second half); returns the DC level
 template <bool STAGE8, int KEEP>
 __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, const M1V_CONST_AS float *rq_t, uint32_t &lds_addr) {
@@ -126,7 +96,7 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
     for (int i = 0; i < 8; i++) {
         float c[8];
         m1vf::fdct_col_f<float>(rows.get(0, i), rows.get(1, i), rows.get(2, i), rows.get(3, i), rows.get(4, i), rows.get(5, i),
-                                rows.get(6, i), rows.get(7, i), c, i == 0 ? 8.0f * m1vf::kPxBiasF : 0.0f);
+                                rows.get(6, i), rows.get(7, i), c, i == 0 ? RowStore<KEEP>::kBias0 : 0.0f);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int q = quant(c[u], rq_t[i * 8 + u]);
@@ -142,7 +112,7 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
 }
 
 #ifndef M1V_TILE_KEEP
-#define M1V_TILE_KEEP 2
+#define M1V_TILE_KEEP 0
 #endif
 // Diagnostic build only (-DM1V_TILE_STAMPS, tools/tile_stamps.py): cycles a wave spends in each phase, kept in scalar
 // registers and added to TileArgs::stamps once at the end (a global atomic inside the row loop would join the vmcnt queue).
@@ -175,7 +145,7 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
 #define M1V_TILE_LEAN false
 #endif
 #ifndef M1V_TILE_WAVES_PER_EU
-#define M1V_TILE_WAVES_PER_EU 7
+#define M1V_TILE_WAVES_PER_EU 6
 #endif
 
 template <bool STAGE8, int R>
@@ -189,7 +159,7 @@ void k_encode_tiles(TileArgs a) {
     const bool chroma = wave == 2; // wave-uniform
     constexpr int kStride = STAGE8 ? kStageStride8 : kStageStride16;
 
-    uint32_t *vlc = lds + kTileVlc, *cnt = lds + kTileCnt, *G = lds + kTileG, *segtab = lds + kTileSegTab, *misc = lds + kTileMisc;
+    uint32_t *vlc = lds + kTileVlc + wave * kVlcWords, *cnt = lds + kTileCnt, *G = lds + kTileG, *segtab = lds + kTileSegTab, *misc = lds + kTileMisc;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const uint32_t region_off = (uint32_t)kTileFixedWords * 4u + (uint32_t)wave * a.luma_region; // bytes from lds
     uint32_t *image = lds + kTileFixedWords + (2u * a.luma_region + a.chroma_region) / 4u;
@@ -221,12 +191,18 @@ void k_encode_tiles(TileArgs a) {
         comp = blk_ < 4 ? 0 : blk_ - 3;
     }
 
-    // ---- the lane's share of the wave's DMA: 16 bytes of every row-step.  Pieces that lie outside the picture region
-    //      (last tile column / row) re-read bytes of the last strip / macroblock row; their lanes are not `valid`. ----
-    const uint32_t step_bytes = chroma ? kChromaStep : kLumaStep;
-    const uint32_t pitch = chroma ? (uint32_t)g.half_w * 3u : (uint32_t)g.W * 3u; // bytes from row i to row i + 1 of a block
-    uint32_t voff_a, voff_b = 0; // byte offsets from the frame base of this lane's 16 bytes of row 0 (first / second instruction)
+    // ---- the lane's share of the wave's DMA.  One row-step = TWO 1-KiB LDS-DMA instructions into a 2-KiB ring slot, the
+    //      same for the luma waves and the chroma wave (no branch, no EXEC mask, one vmcnt count):
+    //        luma    units 0..63 | units 64..95 (lanes 32..63 repeat them into the slot's unused last 512 bytes)
+    //        chroma  macroblock rows 0, 1 (2 x 192 bytes, lanes 0..23; the others repeat) | rows 2, 3, at +1024
+    //      Pieces outside the picture region (last tile column / row) re-read bytes of the last strip / macroblock row;
+    //      the lanes that own those blocks are not `valid`. ----
+    uint32_t pitch;          // bytes from row i to row i + 1 of a block
+    uint32_t voff_a, voff_b; // this lane's 16 bytes of row 0 (first / second instruction): byte offset from the frame base
+    uint32_t lane_row;       // LDS address of the lane's 24 bytes inside slot 0
+    const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
     if (!chroma) {
+        pitch = (uint32_t)g.W * 3u;
         const uint32_t vw = (uint32_t)strips_here * 48u;
         auto off = [&](uint32_t L) { // L-th 16-byte unit of the 1536-byte row-step: piece = picture row, `within` inside its 384 bytes
             const uint32_t piece = L / 24u, within = min((L - piece * 24u) * 16u, vw - 16u);
@@ -235,61 +211,60 @@ void k_encode_tiles(TileArgs a) {
         };
         voff_a = off((uint32_t)lane);
         voff_b = off(64u + (uint32_t)(lane & 31));
+        lane_row = ring + (uint32_t)lane * 24u;
     } else {
+        pitch = (uint32_t)g.half_w * 3u;
         const uint32_t vw = (uint32_t)strips_here * 24u;
         // (an odd number of strips ends in the middle of a 16-byte unit: that unit is still fetched whole — up to 8 bytes
         //  past the tile's last strip, still inside the first quarter of the frame, where all chroma sources lie)
-        const uint32_t L = (uint32_t)min(lane, 47), piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
-        const uint32_t mb = (uint32_t)min(m0 + (int)piece, g.n_mbrows - 1);
-        voff_a = ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
+        const uint32_t L = (uint32_t)lane % 24u, piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
+        auto off = [&](uint32_t mbrow) {
+            const uint32_t mb = (uint32_t)min(m0 + (int)mbrow, g.n_mbrows - 1);
+            return ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
+        };
+        voff_a = off(piece);
+        voff_b = off(2u + piece);
+        const uint32_t mrow = ((uint32_t)lane >> 3) & 3u;
+        lane_row = ring + (mrow >> 1) * 1024u + (mrow & 1u) * 192u + ((uint32_t)lane & 7u) * 24u;
     }
-    const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
-    auto issue_row = [&](int r) {            // row-step r -> slot r % R
+    constexpr uint32_t kSlot = 2048;
+    auto issue_row = [&](int r) { // row-step r -> slot r % R.  M0 (the LDS destination) is set once: the second instruction's
+                                  // offset:1024 moves its LDS address AND its source address, so its base is 1024 lower
         const uint8_t *sb = fbase + (size_t)r * pitch;
-        const uint32_t dst = ring + (uint32_t)(r % R) * step_bytes;
-        if (!chroma) {
-            dma16(voff_a, dst, sb);
-            if (lane < 32) dma16(voff_b, dst + 1024u, sb);
-        } else {
-            if (lane < 48) dma16(voff_a, dst, sb);
-        }
+        const uint32_t dst = ring + (uint32_t)(r % R) * kSlot;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_a), "v"(voff_b), "s"(dst), "s"(sb), "s"(sb - 1024));
     };
 
-    // ---- everything this wave needs from memory, requested up front: its quarter of the VLC table, R row-steps ----
+    // ---- everything this wave needs from memory, requested up front: its own copy of the VLC table (a wave reads only its
+    //      own copy, so the waves of a tile do not meet before the bit counts are exchanged), then R row-steps ----
     TSTAMP_INIT();
-    dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kWave) * 4u, a.tab->vlc + wave * kWave);
+#pragma unroll
+    for (int q = 0; q < kVlcWords / kWave; q++)
+        dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kVlcWords + q * kWave) * 4u, a.tab->vlc + q * kWave);
 #pragma unroll
     for (int r = 0; r < R; r++) issue_row(r);
-
+    // (the image is first touched in pass 2, behind the barrier of the bit counts)
     for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
-    // VLC table landed (the oldest request), image cleared: visible to all waves behind this barrier.  The first row-step is
-    // still on its way, so nobody waits here for longer than for its own pixels.
     TSTAMP(0);
-    if (chroma) wait_vm<R * 1>(); else wait_vm<R * 2>();
-    lds_barrier();
     TSTAMP(1);
 
     // ---- pixel stage: rows out of the ring as they land, the freed slot refilled with row i + R ----
     const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
     const CompCoefF kf = comp_coef_f(comp);
-    const uint32_t lane_row = ring + (uint32_t)(chroma ? (lane & 31) : lane) * 24u;
     RowStore<M1V_TILE_KEEP> rows;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int newest = (i - 1 + R < 7) ? (i - 1 + R) : 7; // newest row-step requested so far
-        const int behind = newest - i;                         // row-steps that may still be in flight
-        if (chroma) {
-            if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<1>(); else if (behind == 2) wait_vm<2>();
-            else if (behind == 3) wait_vm<3>(); else if (behind == 4) wait_vm<4>(); else if (behind == 5) wait_vm<5>();
-            else if (behind == 6) wait_vm<6>(); else wait_vm<7>();
-        } else {
-            if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<2>(); else if (behind == 2) wait_vm<4>();
-            else if (behind == 3) wait_vm<6>(); else if (behind == 4) wait_vm<8>(); else if (behind == 5) wait_vm<10>();
-            else if (behind == 6) wait_vm<12>(); else wait_vm<14>();
-        }
-        const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * step_bytes);
+        const int behind = newest - i;                         // row-steps that may still be in flight: two instructions each
+        if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<2>(); else if (behind == 2) wait_vm<4>();
+        else if (behind == 3) wait_vm<6>(); else if (behind == 4) wait_vm<8>(); else if (behind == 5) wait_vm<10>();
+        else if (behind == 6) wait_vm<12>(); else wait_vm<14>();
+        const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * kSlot);
         if (i + R < 8) issue_row(i + R);
         float px[8];
         convert_row<3, M1V_TILE_LEAN>(v, kf, px);
@@ -322,7 +297,11 @@ void k_encode_tiles(TileArgs a) {
     BlockBits bb = {0, 0};
     dc_header(dc, blk < 4, blk, vlc, hdr, hlen);
     const unsigned long long emit = emit_set(nz);
+#if defined(M1V_TILE_PASS1_SINGLE)
     block_bits_pass1<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
+#else
+    block_bits_pass1_pairs<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
+#endif
     if (!valid) {
         bb.tot = 0;
         bad = 0;
