@@ -23,7 +23,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_profile_read_times", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
-    "m1v_debug_set_input_mode", "m1v_reserve_scratch", "m1v_scratch_bytes", "m1v_debug_set_path", "m1v_path_in_use",
+    "m1v_debug_set_input_mode", "m1v_reserve_scratch", "m1v_scratch_bytes", "m1v_debug_set_path", "m1v_path_in_use", "m1v_debug_fail_alloc",
 ]
 
 
@@ -108,6 +108,8 @@ def lib():
     L.m1v_debug_set_path.restype = C.c_int
     L.m1v_path_in_use.argtypes = [vp]
     L.m1v_path_in_use.restype = C.c_int
+    L.m1v_debug_fail_alloc.argtypes = [C.c_int]
+    L.m1v_debug_fail_alloc.restype = None
     L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.mpeg_encode_procedure.restype = C.c_int
     L.mpeg_encode_procedure_region.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]

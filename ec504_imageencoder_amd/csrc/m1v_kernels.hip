@@ -742,20 +742,22 @@ template <bool STAGE8>
 __device__ __forceinline__ unsigned long long stage_nonzero_mask(const uint32_t *blk, uint32_t lds_addr) {
     constexpr int kWords = STAGE8 ? 16 : 32;
     uint32_t w[kWords];
-    // the staging stores are inline asm (block_to_stage), so the reads are too, chained behind them by lds_addr
+    // The staging stores are inline asm (block_to_stage), so the reads are too, chained behind them by lds_addr.  Eight
+    // ds_read2_b32 AND their s_waitcnt in ONE statement: the compiler's waitcnt pass does not see LDS operations inside asm,
+    // so nothing may sit between a read and the wait that covers it (a register copy there would copy stale bits).
     unsigned long long pr[kWords / 2];
 #pragma unroll
-    for (int j = 0; j < kWords / 2; j += 4)
-        asm("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%7 offset1:%8\n\t"
-            "ds_read2_b32 %2, %4 offset0:%9 offset1:%10\n\tds_read2_b32 %3, %4 offset0:%11 offset1:%12"
-            : "=&v"(pr[j]), "=&v"(pr[j + 1]), "=&v"(pr[j + 2]), "=&v"(pr[j + 3]), "+v"(lds_addr)
-            : "n"(2 * j), "n"(2 * j + 1), "n"(2 * j + 2), "n"(2 * j + 3), "n"(2 * j + 4), "n"(2 * j + 5), "n"(2 * j + 6),
-              "n"(2 * j + 7));
-#pragma unroll
     for (int j = 0; j < kWords / 2; j += 8)
-        asm("s_waitcnt lgkmcnt(0)"
-            : "+v"(pr[j]), "+v"(pr[j + 1]), "+v"(pr[j + 2]), "+v"(pr[j + 3]), "+v"(pr[j + 4]), "+v"(pr[j + 5]),
-              "+v"(pr[j + 6]), "+v"(pr[j + 7]));
+        asm("ds_read2_b32 %0, %8 offset0:%9 offset1:%10\n\tds_read2_b32 %1, %8 offset0:%11 offset1:%12\n\t"
+            "ds_read2_b32 %2, %8 offset0:%13 offset1:%14\n\tds_read2_b32 %3, %8 offset0:%15 offset1:%16\n\t"
+            "ds_read2_b32 %4, %8 offset0:%17 offset1:%18\n\tds_read2_b32 %5, %8 offset0:%19 offset1:%20\n\t"
+            "ds_read2_b32 %6, %8 offset0:%21 offset1:%22\n\tds_read2_b32 %7, %8 offset0:%23 offset1:%24\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(pr[j]), "=&v"(pr[j + 1]), "=&v"(pr[j + 2]), "=&v"(pr[j + 3]), "=&v"(pr[j + 4]), "=&v"(pr[j + 5]),
+              "=&v"(pr[j + 6]), "=&v"(pr[j + 7]), "+v"(lds_addr)
+            : "n"(2 * j), "n"(2 * j + 1), "n"(2 * j + 2), "n"(2 * j + 3), "n"(2 * j + 4), "n"(2 * j + 5), "n"(2 * j + 6),
+              "n"(2 * j + 7), "n"(2 * j + 8), "n"(2 * j + 9), "n"(2 * j + 10), "n"(2 * j + 11), "n"(2 * j + 12),
+              "n"(2 * j + 13), "n"(2 * j + 14), "n"(2 * j + 15));
 #pragma unroll
     for (int j = 0; j < kWords / 2; j++) {
         w[2 * j] = (uint32_t)pr[j];
@@ -1684,6 +1686,7 @@ struct m1v_encoder {
     // hooks force (m1v_debug_set_path, a forced input mode, a forced run length).
     int forced_path;   // -1 = by geometry, 0 = runs, 1 = tiles
     int forced_T;      // run length forced by m1v_debug_set_dense_threads (0 = default)
+    bool prefer_tiles; // set (for good) by the first batch whose buffer is not 4-byte aligned
     bool tiles;        // the path configure_path set up
     int tile_cols, tile_rows, tiles_per_frame, tile_ring;
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
@@ -1768,6 +1771,11 @@ size_t m1v_file_prolog(uint8_t out[27]) {
 #ifndef M1V_TILE_RING
 #define M1V_TILE_RING 2
 #endif
+static int g_fail_alloc_in = 0; // test hook (m1v_debug_fail_alloc): the n-th allocation of configure_path from now fails
+static hipError_t plan_malloc(void **p, size_t bytes) {
+    if (g_fail_alloc_in > 0 && --g_fail_alloc_in == 0) return hipErrorOutOfMemory;
+    return hipMalloc(p, bytes);
+}
 static int configure_path(m1v_encoder *e) {
     const int dense_T = e->forced_T;
     const Geometry &g = e->g;
@@ -1781,7 +1789,11 @@ static int configure_path(m1v_encoder *e) {
         size_t arena_off;
         int image_words;
     } plan = {};
-    plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0);
+    // Tiles by default wherever the run kernel cannot use its aligned 24-byte row loads (widths that are not a multiple of 8,
+    // buffers off a 4-byte boundary): there the tile kernel is 1.3-4x faster (profiles/r03_paths_by_geometry.txt).  On
+    // aligned pictures the two kernels run within 1-2 % of each other and the run kernel's gather is cheaper.
+    plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0) &&
+                 (e->forced_path == 1 || !e->fast_ok || e->prefer_tiles);
     size_t need, meta = 0, pre = 0;
     if (plan.tiles) {
         plan.tile_cols = (g.n_strips + kTileStrips - 1) / kTileStrips;
@@ -1843,9 +1855,9 @@ static int configure_path(m1v_encoder *e) {
         f.new_scratch = need != e->scratch_bytes || !bt.scratch;
         const void *have_meta = plan.tiles ? (const void *)bt.seg : (const void *)bt.run_meta;
         f.new_meta = meta != 0 && (meta != e->meta_bytes || plan.tiles != e->tiles || !have_meta);
-        if (f.new_scratch) ok = hipMalloc(&f.scratch, need) == hipSuccess;
-        if (ok && f.new_meta) ok = hipMalloc(&f.meta, meta) == hipSuccess;
-        if (ok && f.new_meta && pre) ok = hipMalloc(&f.pre, pre) == hipSuccess;
+        if (f.new_scratch) ok = plan_malloc((void **)&f.scratch, need) == hipSuccess;
+        if (ok && f.new_meta) ok = plan_malloc(&f.meta, meta) == hipSuccess;
+        if (ok && f.new_meta && pre) ok = plan_malloc(&f.pre, pre) == hipSuccess;
     }
     if (!ok) {
         for (Fresh &f : fresh) {
@@ -1944,6 +1956,7 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->forced_mode = -1;
     e->forced_path = -1;
     e->forced_T = 0;
+    e->prefer_tiles = false;
     e->tiles = false;
     e->tile_cols = e->tile_rows = e->tiles_per_frame = e->tile_ring = 0;
     e->luma_region = e->chroma_region = 0;
@@ -2119,6 +2132,8 @@ int m1v_debug_set_path(m1v_encoder *e, int path) {
 
 int m1v_path_in_use(const m1v_encoder *e) { return e ? (e->tiles ? 1 : 0) : -1; }
 
+void m1v_debug_fail_alloc(int nth) { g_fail_alloc_in = nth > 0 ? nth : 0; }
+
 #if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS)
 // diagnostic builds only: read and clear the per-phase cycle sums
 int m1v_debug_read_stamps(m1v_encoder *e, unsigned long long out[32]) {
@@ -2192,6 +2207,15 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     if (n_frames < 0 || n_frames > e->max_frames) return fail(M1V_E_ARG, "n_frames exceeds max_frames%s");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(e->device));
+    if (!e->tiles && e->g.C == 3 && e->forced_path < 0 && e->forced_mode < 0 && e->forced_T == 0 && ((uintptr_t)d_rgb & 3) != 0) {
+        // a buffer off a 4-byte boundary would send the run kernel to its byte loads: from now on this encoder uses tiles
+        // (one reconfiguration: the device is drained and the scratch of the other kernel allocated)
+        HIP_TRY(hipDeviceSynchronize());
+        for (m1v_encoder::Batch &b : e->batch) b.gather_pending = false;
+        e->prefer_tiles = true;
+        const int rc = configure_path(e);
+        if (rc != M1V_OK) return rc;
+    }
     m1v_encoder::Batch &bt = e->batch[e->pipelined ? (e->calls++ & 1u) : 0];
     hipStream_t gs = e->pipelined ? e->side : st;   // stream of the layout + gather kernels
     if (e->pipelined && bt.gather_pending)           // this set's previous gather must have drained its scratch

@@ -174,6 +174,10 @@ int m1v_debug_set_lds_words(m1v_encoder *enc, int words);
  * produce the same bytes.  Test hook: -1 = by geometry, 0 = runs, 1 = tiles (3 channels only). */
 int m1v_debug_set_path(m1v_encoder *enc, int path);
 int m1v_path_in_use(const m1v_encoder *enc); /* 1 = tiles, 0 = runs */
+/* Test hook: the nth device allocation made from now on by a reconfiguration (m1v_reserve_scratch, m1v_set_pipelined,
+ * the m1v_debug_set_* hooks) fails as if the device were out of memory; 0 = off.  A failed reconfiguration returns
+ * M1V_E_HIP and leaves the encoder exactly as it was. */
+void m1v_debug_fail_alloc(int nth);
 /* Test hook: force how the RUN kernel loads its pixels (forcing a mode selects the run path): -1 = automatic (by width,
  * channel count and pointer alignment), 0 = byte loads (valid everywhere), 2 = 28-byte loads + funnel shift (3 channels,
  * 4-byte aligned buffer).  A mode that is not valid for the buffer at hand is ignored.  Lets tests compare the load paths

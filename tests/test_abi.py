@@ -185,3 +185,61 @@ def test_hot_kernel_shape_of_round_2(built):
     assert count("ds_write_b8") == 64
     assert count("v_floor_f32") == 112 and count("v_min3_f32") == 32
     assert count("s_barrier") <= 4, count("s_barrier")
+
+
+def _gfx950_disassembly():
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = os.path.join(ROOT, "ec504_imageencoder_amd", "csrc", "m1v_kernels.o")
+    if not (os.path.exists(objdump) and os.path.exists(obj)):
+        pytest.skip("llvm tools or object absent")
+    import glob
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(obj, os.path.join(td, "k.o"))
+        subprocess.run([objdump, "--offloading", "k.o"], cwd=td, capture_output=True, text=True)
+        cos = glob.glob(os.path.join(td, "k.o.*gfx950*"))
+        if not cos:
+            pytest.skip("cannot extract the gfx950 code object")
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readobj", "--notes", cos[0]], capture_output=True, text=True).stdout
+        return subprocess.run([objdump, "-d", cos[0]], capture_output=True, text=True).stdout, notes
+
+
+def test_tile_kernel_shape_of_round_3(built):
+    """Round-3 properties of the tile kernel (csrc/m1v_tiles.h), read off the code object:
+    * its pixels arrive by LDS-DMA only: 16 global_load_lds_dwordx4 (two per row-step) and 3 global_load_lds_dword (the
+      wave's VLC table), no global_load into registers;
+    * the ring is two row-steps deep and every row is read as soon as ITS two instructions have landed: the vmcnt waits
+      of the row loop are 2, 2, 2, 2, 2, 2, 2, 0 (one wait per row, no branch between the wave kinds);
+    * the waves of a tile meet twice on the common path (bit counts, image complete);
+    * 72 VGPRs or fewer (7 waves per SIMD by registers; LDS admits 8 tiles = 6 waves per SIMD) and NO scratch: a spill
+      would also join the vmcnt queue the row loop counts on;
+    * every LDS read issued from inline asm has its s_waitcnt in the same statement (nothing can sit between them)."""
+    asm, notes = _gfx950_disassembly()
+    for variant in ("k_encode_tilesILb1", "k_encode_tilesILb0"):
+        m = re.search(r"<_ZN\S*%s\S*>:\n(.*?)\n\n" % variant, asm, re.S)
+        assert m, variant
+        lines = [l.split("//")[0].strip() for l in m.group(1).splitlines() if l.strip() and not l.strip().startswith(("/", ";"))]
+        ops = [l.split()[0] for l in lines]
+        count = lambda name: sum(1 for o in ops if o.startswith(name))
+        assert count("global_load_lds_dwordx4") == 16 and count("global_load_lds_dword") == 19, variant
+        assert count("global_load_dword") == 0 and count("scratch_") == 0 and count("flat_load") == 0, variant
+        first_read = next(i for i, l in enumerate(lines) if l.startswith("ds_read_b64"))
+        waits = [int(x) for l in lines[:first_read + 2500] for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", l)]
+        assert waits[:8] == [2, 2, 2, 2, 2, 2, 2, 0], (variant, waits[:12])
+        assert count("s_barrier") <= 4, (variant, count("s_barrier"))   # 2 on the common path + 2 on the arena fallback
+        # asm LDS reads: the three ds_read_b64 of a row (offsets 0, 8, 16) and the ds_read2_b32 groups of the mask are each
+        # followed directly by their wait
+        rows = [i for i, l in enumerate(lines) if l.startswith("ds_read_b64") and l.endswith("offset:16")
+                and lines[i - 1].startswith("ds_read_b64") and lines[i - 1].endswith("offset:8")]
+        assert len(rows) == 8, (variant, len(rows))
+        for i in rows:
+            assert lines[i + 1].startswith("s_waitcnt lgkmcnt(0)"), (variant, lines[i:i + 2])
+        groups = [i for i, l in enumerate(lines) if l.startswith("ds_read2_b32") and not lines[i + 1].startswith("ds_read2_b32")]
+        assert groups, variant
+        for i in groups:
+            assert lines[i + 1].startswith("s_waitcnt lgkmcnt(0)"), (variant, lines[i:i + 2])
+    recs = re.findall(r"\.name:\s*(\S*k_encode_tiles\S*).*?\.private_segment_fixed_size:\s*(\d+).*?\.vgpr_count:\s*(\d+)", notes, re.S)
+    assert len(recs) == 2, recs
+    for nm, scratch, vgprs in recs:
+        assert int(scratch) == 0 and int(vgprs) <= 72, (nm, scratch, vgprs)

@@ -131,11 +131,63 @@ def test_colour_inside_the_encode_kernels_ties_and_sample(torch_cuda, orc, mode)
     _check_colours_through(torch_cuda, orc, np.concatenate([ties, sample]), configure, channels)
 
 
-def test_colour_inside_the_tile_kernel_exhaustive_2_24(torch_cuda, orc):
-    """Every one of the 2^24 RGB triples through the default encode kernel, coded as Y, Cb and Cr (4096 flat-cell frames)."""
+@pytest.mark.parametrize("path", ["tiles", "runs"])
+def test_colour_inside_the_encode_kernels_exhaustive_2_24(torch_cuda, orc, path):
+    """Every one of the 2^24 RGB triples through each encode kernel, coded as Y, Cb and Cr (4096 flat-cell frames)."""
     v = np.arange(1 << 24, dtype=np.uint32)
     colours = np.stack([v >> 16, (v >> 8) & 255, v & 255], -1).astype(np.uint8)
-    _check_colours_through(torch_cuda, orc, colours, lambda e: None)
+    _check_colours_through(torch_cuda, orc, colours, lambda e: e.debug_set_path(path))
+
+
+@pytest.mark.parametrize("path", ["tiles", "runs"])
+def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path):
+    """m1v_reserve_scratch allocates the worst-case arena; when that allocation fails (injected: the 1st, then the 2nd
+    allocation of the reconfiguration) the call reports M1V_E_HIP and the encoder keeps its previous scratch and
+    geometry: the next batch encodes correctly, and a later reservation succeeds."""
+    from ec504_imageencoder_amd import EncoderError, _ffi
+    W, H, n = 352, 288, 3
+    enc = _enc(W, H, max_frames=n)
+    enc.debug_set_path(path)
+    rgb = enc.synth(n, seed=31)
+    want, _ = orc.encode_frames(rgb.cpu().numpy(), n, W, H, 7, 12, orc.MODE_FULL)
+    assert enc.encode_to_bytes(rgb, 7)[0] == want
+    before = enc.scratch_bytes()
+    for nth in (1, 2):
+        _ffi.lib().m1v_debug_fail_alloc(nth)
+        with pytest.raises(EncoderError) as ei:
+            enc.reserve_scratch(True)
+        assert ei.value.code == _ffi.E_HIP
+        _ffi.lib().m1v_debug_fail_alloc(0)
+        assert enc.scratch_bytes() == before and enc.path == path
+        assert enc.encode_to_bytes(rgb, 7)[0] == want
+    enc.reserve_scratch(True)
+    assert enc.scratch_bytes() > before
+    assert enc.encode_to_bytes(rgb, 7)[0] == want
+    enc.close()
+
+
+def test_path_is_picked_by_geometry_and_alignment(torch_cuda, orc):
+    """Aligned 3-channel pictures (width % 8 == 0, 4-byte aligned buffer) take the run kernel, every other 3-channel
+    input the tile kernel; an encoder that meets a misaligned buffer switches to tiles for good.  Same bytes either way."""
+    torch = torch_cuda
+    for W, want_path in ((352, "runs"), (356, "tiles"), (350, "tiles")):
+        enc = _enc(W, 288, max_frames=2)
+        assert enc.path == want_path, (W, enc.path)
+        enc.close()
+    enc4 = _enc(352, 288, channels=4, max_frames=2)
+    assert enc4.path == "runs"
+    enc4.close()
+    W, H, n = 352, 288, 2
+    rgb = np.random.default_rng(9).integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    want, _ = orc.encode_frames(rgb, n, W, H, 0, 12, orc.MODE_FULL)
+    flat = torch.empty(rgb.size + 16, dtype=torch.uint8, device="cuda")
+    enc = _enc(W, H, max_frames=n)
+    for shift, path_after in ((0, "runs"), (2, "tiles"), (0, "tiles")):
+        dev = flat[shift:shift + rgb.size].view(n, H, W, 3)
+        dev.copy_(torch.from_numpy(rgb))
+        got, _ = enc.encode_to_bytes(dev, 0)
+        assert got == want and enc.path == path_after, (shift, enc.path)
+    enc.close()
 
 
 def test_subsample(torch_cuda, orc):
