@@ -2080,10 +2080,13 @@ int m1v_set_pipelined(m1v_encoder *e, int enable) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     for (m1v_encoder::Batch &bt : e->batch) bt.gather_pending = false;
+    const bool before = e->pipelined;
     e->pipelined = enable != 0;
     e->calls = 0;
     if (e->pipelined && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    return configure_path(e);
+    const int rc = configure_path(e);
+    if (rc != M1V_OK) e->pipelined = before; // the second set of buffers could not be allocated: stay as we were
+    return rc;
 }
 
 int m1v_flush(m1v_encoder *e, void *stream) {

@@ -141,9 +141,9 @@ def test_colour_inside_the_encode_kernels_exhaustive_2_24(torch_cuda, orc, path)
 
 @pytest.mark.parametrize("path", ["tiles", "runs"])
 def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path):
-    """m1v_reserve_scratch allocates the worst-case arena; when that allocation fails (injected: the 1st, then the 2nd
-    allocation of the reconfiguration) the call reports M1V_E_HIP and the encoder keeps its previous scratch and
-    geometry: the next batch encodes correctly, and a later reservation succeeds."""
+    """m1v_reserve_scratch allocates the worst-case arena, m1v_set_pipelined a second set of buffers; when one of those
+    allocations fails (injected) the call reports M1V_E_HIP and the encoder keeps its previous scratch, geometry and
+    mode: the next batch encodes correctly, and a later reservation succeeds."""
     from ec504_imageencoder_amd import EncoderError, _ffi
     W, H, n = 352, 288, 3
     enc = _enc(W, H, max_frames=n)
@@ -152,10 +152,11 @@ def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path)
     want, _ = orc.encode_frames(rgb.cpu().numpy(), n, W, H, 7, 12, orc.MODE_FULL)
     assert enc.encode_to_bytes(rgb, 7)[0] == want
     before = enc.scratch_bytes()
-    for nth in (1, 2):
+    # (what fails: the only allocation of the arena reservation; the second of the three that pipelined mode needs)
+    for nth, reconfigure in ((1, lambda: enc.reserve_scratch(True)), (2, lambda: enc.set_pipelined(True))):
         _ffi.lib().m1v_debug_fail_alloc(nth)
         with pytest.raises(EncoderError) as ei:
-            enc.reserve_scratch(True)
+            reconfigure()
         assert ei.value.code == _ffi.E_HIP
         _ffi.lib().m1v_debug_fail_alloc(0)
         assert enc.scratch_bytes() == before and enc.path == path
