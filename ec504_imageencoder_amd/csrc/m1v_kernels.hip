@@ -23,7 +23,7 @@
 //   k_encode_strips   one 64-lane workgroup per (frame, strip) for small pictures (< 64 blocks/strip)
 //   k_dense_frame_layout / k_frame_layout   per frame: strip bit/byte counts -> offsets
 //   k_frame_offsets   exclusive scan of frame sizes
-//   k_gather_dense / k_gather   strips -> final positions (funnel shift for non-aligned run pieces),
+//   k_gather_segments (m1v_tiles.h) / k_gather   strips -> final positions (funnel shift of the run / tile segments),
 //                     frame headers, 16-bit length back-patch, trailer
 //   k_coefficients    FDCT+quant+zigzag only (BASELINE config 2)
 //   k_convert, k_subsample, k_synth   plane conversion / 4:2:0 / synthetic input
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
 // into runs of T consecutive blocks, one workgroup (T lanes, no idle lane) per run.  T <= blocks per
 // strip, so a run touches at most two strips: segment 0 (lanes < nA) continues or starts strip s0,
 // segment 1 (lanes >= nA) starts strip s0+1.  Each segment is packed on its own from a word boundary of
-// the workgroup's image (with the 38-bit slice header in front when it starts a strip); k_gather_dense
+// the workgroup's image (with the 38-bit slice header in front when it starts a strip); k_gather_segments
 // later concatenates the segments of a strip with the necessary bit shift.
 struct DenseArgs {
     Geometry g;
@@ -1287,19 +1287,11 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
     return m[1];
 }
 
-// Per strip: where its segments live and how many bits each has, precomputed once so that the gather needs one
-// (scalar, workgroup-uniform) load instead of a chain of metadata loads and integer divisions.
-constexpr int kMaxSeg = 6;
-struct StripDesc {
-    uint32_t n;                 // number of segments, or ~0u: more than kMaxSeg (tiny run lengths) -> generic walk
-    uint32_t src_off[kMaxSeg];  // where the segment starts: offset from the scratch base in 4-byte words
-    uint32_t bits[kMaxSeg];
-    uint32_t pad[3];
-};
-
-// One workgroup per frame: segment bits -> strip descriptors and byte counts -> exclusive scan of the strips.
-__global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, const uint32_t *run_meta, uint32_t *strip_bytes,
-                                                            uint32_t *strip_off, StripDesc *desc,
+// One workgroup per frame: the run segments of every strip, in the form the gather takes them (k_gather_segments in
+// m1v_tiles.h): seg[frame][strip][q] = (bits, where) and seg_pre = the bit offset of segment q inside its strip, padded with
+// empty segments up to `segs` per strip; then strip byte counts and the exclusive scan of the strips.
+__global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int segs, const uint32_t *run_meta, uint2 *seg,
+                                                            uint32_t *seg_pre, uint32_t *strip_bytes, uint32_t *strip_off,
                                                             unsigned long long *frame_size) {
     __shared__ uint32_t ws[32];
     const int f = blockIdx.x;
@@ -1310,25 +1302,15 @@ __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, const u
         uint32_t nbytes = 0;
         if (s < d.n_strips) {
             const size_t i = (size_t)f * d.n_strips + s;
-            int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
+            const int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T; // w_hi - w_lo + 1 <= segs
             uint32_t bits = 0;
-            StripDesc sd;
-            sd.n = (w_hi - w_lo + 1) <= kMaxSeg ? (uint32_t)(w_hi - w_lo + 1) : ~0u;
-#pragma unroll
-            for (int k = 0; k < kMaxSeg; k++) sd.src_off[k] = sd.bits[k] = 0;
-            sd.pad[0] = sd.pad[1] = sd.pad[2] = 0;
-            for (int w = w_lo; w <= w_hi; w++) {
-                uint32_t boff, L = dense_segment(d, mf, w, s, boff);
-                int k = w - w_lo;
-#pragma unroll
-                for (int kk = 0; kk < kMaxSeg; kk++)
-                    if (kk == k) {
-                        sd.src_off[kk] = boff;
-                        sd.bits[kk] = L;
-                    }
+            for (int q = 0; q < segs; q++) {
+                uint32_t boff = 0, L = 0;
+                if (w_lo + q <= w_hi) L = dense_segment(d, mf, w_lo + q, s, boff);
+                seg[i * segs + q] = make_uint2(L, boff);
+                seg_pre[i * segs + q] = bits;
                 bits += L;
             }
-            desc[i] = sd;
             nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
             strip_bytes[i] = nbytes;
         }
@@ -1339,19 +1321,6 @@ __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, const u
     }
     if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
 }
-
-struct DenseGatherArgs {
-    DenseGeom d;
-    const uint8_t *scratch;
-    const uint32_t *run_meta, *strip_bytes, *strip_off;
-    const StripDesc *desc;
-    const unsigned long long *frame_size, *frame_off;
-    const Tables *tab;
-    uint8_t *out;
-    unsigned long long out_cap;
-    uint32_t *status;
-    int first_index;
-};
 
 // 32 bits [lo_bit, lo_bit + 32) of a strip that is the concatenation of segments (src, bits): a 64-bit window of
 // the source segment (word loads from the word-aligned scratch), funnel-shifted to the destination phase.
@@ -1366,51 +1335,10 @@ __device__ __forceinline__ uint32_t strip_bits_from(const uint8_t *seg_base, uin
     return bits << (32u - (lo - lo_bit) - nb);
 }
 
-#ifndef M1V_GATHER_THREADS
-#define M1V_GATHER_THREADS 64
+#ifndef M1V_GATHER_STRIPS
+#define M1V_GATHER_STRIPS 4
 #endif
-constexpr int kGatherThreads = M1V_GATHER_THREADS;
-__global__ __launch_bounds__(256) void k_gather_dense(DenseGatherArgs a) {
-    const DenseGeom &d = a.d;
-    int s = blockIdx.x, f = blockIdx.y;
-    unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
-    if (fo + fs > a.out_cap) {
-        if (threadIdx.x == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
-        return;
-    }
-    size_t idx = (size_t)f * d.n_strips + s;
-    uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
-    uint32_t n = a.strip_bytes[idx];
-    const uint32_t nwords = (n + 3) >> 2;
-    const StripDesc sd = a.desc[idx]; // workgroup-uniform: scalar loads
-    for (uint32_t j = threadIdx.x; j < nwords; j += blockDim.x) {
-        uint32_t lo_bit = 32u * j, val = 0, D = 0;
-        if (sd.n != ~0u) {
-#pragma unroll
-            for (int k = 0; k < kMaxSeg; k++)
-                if ((uint32_t)k < sd.n) {
-                    val |= strip_bits_from(a.scratch + (size_t)sd.src_off[k] * 4, D, sd.bits[k], lo_bit);
-                    D += sd.bits[k];
-                }
-        } else { // many short runs per strip: walk the run metadata
-            const uint32_t *mf = a.run_meta + (size_t)f * d.runs_per_frame * 4;
-            int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T;
-            for (int w = w_lo; w <= w_hi; w++) {
-                uint32_t boff, L = dense_segment(d, mf, w, s, boff);
-                val |= strip_bits_from(a.scratch + (size_t)boff * 4, D, L, lo_bit);
-                D += L;
-            }
-        }
-        uint32_t b0 = 4u * j;
-        uint8_t *o = dst + b0;
-        if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
-            *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
-        } else {
-            for (uint32_t k = 0; k < 4u && b0 + k < n; k++) o[k] = (uint8_t)(val >> (24u - 8u * k));
-        }
-    }
-    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
-}
+constexpr int kGatherStrips = M1V_GATHER_STRIPS; // strips (one wave each) per gather workgroup
 
 #include "m1v_tiles.h"
 
@@ -1690,17 +1618,17 @@ struct m1v_encoder {
     bool tiles;        // the path configure_path set up
     int tile_cols, tile_rows, tiles_per_frame, tile_ring;
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
-    size_t meta_bytes;      // size of run_meta (runs) or seg (tiles) in effect
+    size_t meta_bytes, seg_bytes; // sizes of run_meta and seg in effect
+    int segs;               // segments per strip: tile rows (tiles), or the most runs a strip can touch (run kernels)
     Tables *d_tab;
     // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
     // pipelined mode batch k+1 can encode while batch k is still being gathered.
     struct Batch {
         uint8_t *scratch;
-        uint32_t *run_meta;     // runs path
-        uint2 *seg;             // tiles path: [frame][strip][tile row] (bits, where)
-        uint32_t *seg_pre;      //             bit offset of each segment inside its strip
+        uint32_t *run_meta;     // run kernels: [frame][run][4]
+        uint2 *seg;             // [frame][strip][segment] (bits, where): what a strip is concatenated from
+        uint32_t *seg_pre;      // bit offset of each segment inside its strip
         uint32_t *strip_bytes, *strip_off;
-        StripDesc *strip_desc;
         unsigned long long *frame_size, *frame_off;
         uint32_t *status;
         hipEvent_t enc_done, gather_done;
@@ -1794,7 +1722,8 @@ static int configure_path(m1v_encoder *e) {
     // aligned pictures the two kernels run within 1-2 % of each other and the run kernel's gather is cheaper.
     plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0) &&
                  (e->forced_path == 1 || !e->fast_ok || e->prefer_tiles);
-    size_t need, meta = 0, pre = 0;
+    size_t need, meta = 0, segb = 0;
+    int segs = 0; // segments per strip
     if (plan.tiles) {
         plan.tile_cols = (g.n_strips + kTileStrips - 1) / kTileStrips;
         plan.tile_rows = (g.n_mbrows + kTileMbRows - 1) / kTileMbRows;
@@ -1813,8 +1742,7 @@ static int configure_path(m1v_encoder *e) {
         plan.arena_off = runs * plan.slot_bytes;
         need = plan.arena_off + (size_t)plan.arena_slots * plan.run_cap;
         if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
-        meta = (size_t)e->max_frames * g.n_strips * plan.tile_rows * sizeof(uint2);
-        pre = (size_t)e->max_frames * g.n_strips * plan.tile_rows * sizeof(uint32_t);
+        segs = plan.tile_rows;
     } else if (e->dense) {
         int T = dense_T > 0 ? dense_T : (bps >= 256 ? 256 : (bps / kWave) * kWave);
         if (T < kWave || T > 384 || T % kWave || T > bps) return fail(M1V_E_ARG, "bad dense run length%s");
@@ -1839,30 +1767,34 @@ static int configure_path(m1v_encoder *e) {
         need = plan.arena_off + (size_t)plan.arena_slots * plan.run_cap;
         if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
         meta = runs * 4 * sizeof(uint32_t);
+        segs = (bps + T - 1) / T + 1; // the most runs whose blocks one strip can hold
     } else {
         need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
     }
     const int sets = e->pipelined ? 2 : 1;
+    segb = (size_t)e->max_frames * g.n_strips * segs * sizeof(uint2);
     struct Fresh {
         uint8_t *scratch;
-        void *meta, *pre;
-        bool new_scratch, new_meta;
+        void *meta, *seg, *pre;
+        bool new_scratch, new_meta, new_seg;
     } fresh[2] = {};
     bool ok = true;
     for (int i = 0; i < sets && ok; i++) {
         const m1v_encoder::Batch &bt = e->batch[i];
         Fresh &f = fresh[i];
         f.new_scratch = need != e->scratch_bytes || !bt.scratch;
-        const void *have_meta = plan.tiles ? (const void *)bt.seg : (const void *)bt.run_meta;
-        f.new_meta = meta != 0 && (meta != e->meta_bytes || plan.tiles != e->tiles || !have_meta);
+        f.new_meta = meta != 0 && (meta != e->meta_bytes || !bt.run_meta);
+        f.new_seg = segb != 0 && (segb != e->seg_bytes || !bt.seg);
         if (f.new_scratch) ok = plan_malloc((void **)&f.scratch, need) == hipSuccess;
         if (ok && f.new_meta) ok = plan_malloc(&f.meta, meta) == hipSuccess;
-        if (ok && f.new_meta && pre) ok = plan_malloc(&f.pre, pre) == hipSuccess;
+        if (ok && f.new_seg) ok = plan_malloc(&f.seg, segb) == hipSuccess;
+        if (ok && f.new_seg) ok = plan_malloc(&f.pre, segb / 2) == hipSuccess;
     }
     if (!ok) {
         for (Fresh &f : fresh) {
             (void)hipFree(f.scratch);
             (void)hipFree(f.meta);
+            (void)hipFree(f.seg);
             (void)hipFree(f.pre);
         }
         (void)hipGetLastError();
@@ -1877,17 +1809,18 @@ static int configure_path(m1v_encoder *e) {
         }
         if (f.new_meta) {
             (void)hipFree(bt.run_meta);
+            bt.run_meta = (uint32_t *)f.meta;
+        }
+        if (f.new_seg) {
             (void)hipFree(bt.seg);
             (void)hipFree(bt.seg_pre);
-            bt.run_meta = plan.tiles ? nullptr : (uint32_t *)f.meta;
-            bt.seg = plan.tiles ? (uint2 *)f.meta : nullptr;
+            bt.seg = (uint2 *)f.seg;
             bt.seg_pre = (uint32_t *)f.pre;
         }
         size_t nslots = (size_t)e->max_frames * g.n_strips;
         if (!bt.strip_bytes) {
             hipError_t err = hipMalloc(&bt.strip_bytes, nslots * sizeof(uint32_t));
             if (err == hipSuccess) err = hipMalloc(&bt.strip_off, nslots * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipMalloc(&bt.strip_desc, nslots * sizeof(StripDesc));
             if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.status, 4 * sizeof(uint32_t)); // [0] encode status, [1] sink, [2] arena counter
@@ -1905,7 +1838,9 @@ static int configure_path(m1v_encoder *e) {
     e->run_cap = plan.run_cap; e->image_words = plan.image_words; e->slot_bytes = plan.slot_bytes;
     e->arena_slots = plan.arena_slots; e->arena_off = plan.arena_off;
     e->scratch_bytes = need;
-    e->meta_bytes = meta;
+    e->meta_bytes = meta ? meta : e->meta_bytes; // (a path without run metadata keeps the other path's array and its size)
+    e->seg_bytes = segb ? segb : e->seg_bytes;
+    e->segs = segs;
     return M1V_OK;
 }
 
@@ -1960,7 +1895,8 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->tiles = false;
     e->tile_cols = e->tile_rows = e->tiles_per_frame = e->tile_ring = 0;
     e->luma_region = e->chroma_region = 0;
-    e->meta_bytes = 0;
+    e->meta_bytes = e->seg_bytes = 0;
+    e->segs = 0;
     e->runs_per_frame = 0;
     e->run_cap = e->slot_bytes = e->arena_slots = 0;
     e->arena_off = 0;
@@ -2022,7 +1958,6 @@ void m1v_destroy(m1v_encoder *e) {
         (void)hipFree(bt.seg_pre);
         (void)hipFree(bt.strip_bytes);
         (void)hipFree(bt.strip_off);
-        (void)hipFree(bt.strip_desc);
         (void)hipFree(bt.frame_size);
         (void)hipFree(bt.frame_off);
         (void)hipFree(bt.status);
@@ -2243,7 +2178,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
 
-    if (!bt.scratch || (e->tiles ? !bt.seg || !bt.seg_pre : (e->dense && !bt.run_meta)))
+    if (!bt.scratch || ((e->tiles || e->dense) && (!bt.seg || !bt.seg_pre)) || (!e->tiles && e->dense && !bt.run_meta))
         return fail(M1V_E_HIP, "the encoder has no scratch (an earlier allocation failed)%s");
     if (e->tiles) {
         TileArgs a;
@@ -2280,14 +2215,14 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             HIP_TRY(hipEventRecord(bt.enc_done, st));
             HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
         }
-        TileGeom d;
+        SegGeom d;
         d.n_frames = n_frames;
         d.n_strips = g.n_strips;
-        d.tile_rows = e->tile_rows;
+        d.segs = e->tile_rows;
         hipLaunchKernelGGL(k_tile_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.seg, bt.seg_pre, bt.strip_bytes, bt.strip_off,
                            bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
-        TileGatherArgs ga;
+        SegGatherArgs ga;
         ga.d = d;
         ga.scratch = bt.scratch;
         ga.seg = bt.seg;
@@ -2301,8 +2236,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.out_cap = out_cap;
         ga.status = d_status ? d_status : bt.status + 1;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather_tiles, dim3(g.n_strips, n_frames), dim3(kTileGatherThreads),
-                           (size_t)(3 * e->tile_rows + 1) * sizeof(uint32_t), gs, ga);
+        hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
+                           (size_t)kGatherStrips * (3 * e->tile_rows + 1) * sizeof(uint32_t), gs, ga);
         HIP_TRY(hipGetLastError());
     } else if (e->dense) {
         DenseArgs a;
@@ -2365,16 +2300,18 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.bps = g.n_mbrows * 6;
         d.T = e->dense_T;
         d.runs_per_frame = e->runs_per_frame;
-        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.run_meta, bt.strip_bytes,
-                           bt.strip_off, bt.strip_desc, bt.frame_size);
+        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, e->segs, bt.run_meta, bt.seg, bt.seg_pre,
+                           bt.strip_bytes, bt.strip_off, bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
-        DenseGatherArgs ga;
-        ga.d = d;
+        SegGatherArgs ga;
+        ga.d.n_frames = n_frames;
+        ga.d.n_strips = g.n_strips;
+        ga.d.segs = e->segs;
         ga.scratch = bt.scratch;
-        ga.run_meta = bt.run_meta;
+        ga.seg = bt.seg;
+        ga.seg_pre = bt.seg_pre;
         ga.strip_bytes = bt.strip_bytes;
         ga.strip_off = bt.strip_off;
-        ga.desc = bt.strip_desc;
         ga.frame_size = bt.frame_size;
         ga.frame_off = bt.frame_off;
         ga.tab = e->d_tab;
@@ -2382,7 +2319,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.out_cap = out_cap;
         ga.status = d_status ? d_status : bt.status + 1;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather_dense, dim3(g.n_strips, n_frames), dim3(kGatherThreads), 0, gs, ga);
+        hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
+                           (size_t)kGatherStrips * (3 * e->segs + 1) * sizeof(uint32_t), gs, ga);
         HIP_TRY(hipGetLastError());
     } else {
         EncodeArgs a;

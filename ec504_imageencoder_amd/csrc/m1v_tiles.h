@@ -24,7 +24,7 @@
 // Bits.  A tile holds 8 strip SEGMENTS (24 consecutive blocks of the strip's stream each).  Lanes write their block's
 // bit count to LDS in emission order; after ONE barrier every wave scans all 192 counts itself (no second barrier),
 // segments start on word boundaries of the tile's LDS image, and the tile records (bits, where) per segment;
-// k_tile_layout / k_gather_tiles concatenate a strip's segments (encoder.h:442-445).
+// k_tile_layout / k_gather_segments concatenate a strip's segments (encoder.h:442-445).
 
 constexpr int kTileStrips = 8, kTileMbRows = 4;
 constexpr int kTileThreads = kTileStrips * kTileMbRows * 6; // 192
@@ -385,12 +385,12 @@ void k_encode_tiles(TileArgs a) {
 }
 
 // ---- layout and gather for tiles: a strip is the concatenation of its tile_rows segments ---------------------------
-struct TileGeom {
-    int n_frames, n_strips, tile_rows;
+struct SegGeom {
+    int n_frames, n_strips, segs; // segs = segments per strip (tile rows here; k_dense_frame_layout pads to its own count)
 };
 
 // One workgroup per frame: bit prefix of every strip's segments, strip byte counts, exclusive scan of the strips.
-__global__ __launch_bounds__(256) void k_tile_layout(TileGeom d, const uint2 *seg, uint32_t *seg_pre, uint32_t *strip_bytes,
+__global__ __launch_bounds__(256) void k_tile_layout(SegGeom d, const uint2 *seg, uint32_t *seg_pre, uint32_t *strip_bytes,
                                                      uint32_t *strip_off, unsigned long long *frame_size) {
     __shared__ uint32_t ws[32];
     const int f = blockIdx.x;
@@ -401,9 +401,9 @@ __global__ __launch_bounds__(256) void k_tile_layout(TileGeom d, const uint2 *se
         if (s < d.n_strips) {
             const size_t i = (size_t)f * d.n_strips + s;
             uint32_t bits = 0;
-            for (int t = 0; t < d.tile_rows; t++) {
-                seg_pre[i * d.tile_rows + t] = bits;
-                bits += seg[i * d.tile_rows + t].x;
+            for (int t = 0; t < d.segs; t++) {
+                seg_pre[i * d.segs + t] = bits;
+                bits += seg[i * d.segs + t].x;
             }
             nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
             strip_bytes[i] = nbytes;
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256) void k_tile_layout(TileGeom d, const uint2 *se
     if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
 }
 
-struct TileGatherArgs {
-    TileGeom d;
+struct SegGatherArgs {
+    SegGeom d;
     const uint8_t *scratch;
     const uint2 *seg;
     const uint32_t *seg_pre, *strip_bytes, *strip_off;
@@ -429,43 +429,86 @@ struct TileGatherArgs {
     int first_index;
 };
 
-constexpr int kTileGatherThreads = 64;
-__global__ __launch_bounds__(kTileGatherThreads) void k_gather_tiles(TileGatherArgs a) {
-    extern __shared__ uint32_t gl[]; // [tile_rows + 1] bit prefix, [tile_rows] bits, [tile_rows] source word offset
-    const TileGeom &d = a.d;
-    const int s = blockIdx.x, f = blockIdx.y, T = d.tile_rows;
+// One wave per strip, kGatherStrips strips per workgroup ; a wave keeps its strip's segment table in
+// its own part of LDS (written and read by the same wave: no barrier).
+__global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGatherArgs a) {
+    extern __shared__ uint32_t gl_all[]; // per wave: [tile_rows + 1] bit prefix, [tile_rows] bits, [tile_rows] source word offset
+    const SegGeom &d = a.d;
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = (int)blockIdx.x * kGatherStrips + wave, f = blockIdx.y, T = d.segs;
+    if (s >= d.n_strips) return;
     const unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
     if (fo + fs > a.out_cap) {
-        if (threadIdx.x == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
+        if (lane == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
         return;
     }
     const size_t idx = (size_t)f * d.n_strips + s;
+    uint32_t *gl = gl_all + wave * (3 * T + 1);
     uint32_t *pre = gl, *bits = gl + T + 1, *src = gl + 2 * T + 1;
-    for (int t = threadIdx.x; t < T; t += kTileGatherThreads) {
+    for (int t = lane; t < T; t += kWave) {
         const uint2 sg = a.seg[idx * T + t];
         pre[t] = a.seg_pre[idx * T + t];
         bits[t] = sg.x;
         src[t] = sg.y;
     }
     const uint32_t n = a.strip_bytes[idx];
-    if (threadIdx.x == 0) pre[T] = 0xffffffffu;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the table is this wave's own: program order is enough
     uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
     const uint32_t nwords = (n + 3) >> 2;
-    for (uint32_t w = threadIdx.x; w < nwords; w += kTileGatherThreads) {
-        const uint32_t lo_bit = 32u * w;
-        int k = 0; // last segment that starts at or before lo_bit
-        for (int step = 1 << (31 - __builtin_clz((unsigned)T | 1u)); step > 0; step >>= 1)
-            if (k + step < T && pre[k + step] <= lo_bit) k += step;
-        uint32_t val = 0;
-        for (; k < T && pre[k] < lo_bit + 32u; k++) val |= strip_bits_from(a.scratch + (size_t)src[k] * 4, pre[k], bits[k], lo_bit);
-        const uint32_t b0 = 4u * w;
-        uint8_t *o = dst + b0;
-        if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
-            *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
-        } else {
-            for (uint32_t q = 0; q < 4u && b0 + q < n; q++) o[q] = (uint8_t)(val >> (24u - 8u * q));
+    // Four output words per lane and trip: their segment searches, then all source loads (unconditional, masked afterwards),
+    // then the stores — one memory latency per trip, and a strip (~1 KB) is one trip.
+    for (uint32_t w0 = lane; w0 < nwords; w0 += 4 * kWave) {
+        int k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t lo_bit = 32u * (w0 + u * kWave);
+            int kk = 0; // last segment that starts at or before lo_bit
+            for (int step = 1 << (31 - __builtin_clz((unsigned)T | 1u)); step > 0; step >>= 1)
+                if (kk + step < T && pre[kk + step] <= lo_bit) kk += step;
+            k[u] = kk;
+        }
+        unsigned long long win[4][2];
+        uint32_t sh[4][2], nb[4][2], at[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t lo_bit = 32u * (w0 + u * kWave);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int kq = min(k[u] + q, T - 1);
+                const uint32_t D = pre[kq], L = (k[u] + q < T) ? bits[kq] : 0u;
+                const uint32_t lo = max(lo_bit, D), hi = min(lo_bit + 32u, D + L);
+                const bool hit = hi > lo;
+                const uint32_t sb = hit ? lo - D : 0u;
+                nb[u][q] = hit ? hi - lo : 0u;
+                sh[u][q] = sb & 31u;
+                at[u][q] = hit ? lo - lo_bit : 0u;
+                const uint32_t *sp = reinterpret_cast<const uint32_t *>(a.scratch + (size_t)src[kq] * 4) + (sb >> 5);
+                win[u][q] = ((unsigned long long)__builtin_bswap32(sp[0]) << 32) | __builtin_bswap32(sp[1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w = w0 + u * kWave, lo_bit = 32u * w;
+            uint32_t val = 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t b = nb[u][q] ? (uint32_t)((win[u][q] << sh[u][q]) >> (64u - nb[u][q])) : 0u;
+                val |= nb[u][q] ? b << (32u - at[u][q] - nb[u][q]) : 0u;
+            }
+            // (a third segment inside one word: only when a segment is shorter than 32 bits, i.e. a last tile row of one
+            //  macroblock row of all-minimal blocks)
+            for (int kk = k[u] + 2; kk < T && pre[kk] < lo_bit + 32u; kk++)
+                val |= strip_bits_from(a.scratch + (size_t)src[kk] * 4, pre[kk], bits[kk], lo_bit);
+            if (w < nwords) {
+                const uint32_t b0 = 4u * w;
+                uint8_t *o = dst + b0;
+                if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
+                    *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
+                } else {
+                    for (uint32_t q = 0; q < 4u && b0 + q < n; q++) o[q] = (uint8_t)(val >> (24u - 8u * q));
+                }
+            }
         }
     }
-    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
+    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, lane);
 }

@@ -13,8 +13,9 @@ import torch
 vp = C.c_void_p
 W, H, n = 1920, 1080, 300
 libs = {}
-for nm in sys.argv[1:]:
-    path = os.path.join(ROOT, "ec504_imageencoder_amd", "libencoder.so") if nm == "base" else os.path.join(ROOT, "build", f"libencoder_{nm}.so")
+for nm in sys.argv[1:]:                     # name[:path]  (path = runs | tiles, default: the library's choice)
+    lib_nm, _, which = nm.partition(":")
+    path = os.path.join(ROOT, "ec504_imageencoder_amd", "libencoder.so") if lib_nm == "base" else os.path.join(ROOT, "build", f"libencoder_{lib_nm}.so")
     L = C.CDLL(path)
     L.m1v_create.argtypes = [C.POINTER(vp)] + [C.c_int] * 7
     L.m1v_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]
@@ -23,6 +24,9 @@ for nm in sys.argv[1:]:
     L.m1v_frame_bound.restype = C.c_size_t
     h = vp()
     assert L.m1v_create(C.byref(h), 0, W, H, 3, 12, 1, n) == 0
+    if which:
+        L.m1v_debug_set_path.argtypes = [vp, C.c_int]
+        assert L.m1v_debug_set_path(h, {"runs": 0, "tiles": 1}[which]) == 0
     libs[nm] = (L, h)
 dev = torch.device("cuda", 0)
 rgb = torch.empty(n * H * W * 3, dtype=torch.uint8, device=dev)
