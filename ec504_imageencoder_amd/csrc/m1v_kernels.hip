@@ -2485,6 +2485,22 @@ int m1v_coefficients_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, 
     a.tab = e->d_tab;
     a.out = d_coeffs;
     a.n_frames = n_frames;
+    if (e->g.C == 3 && e->forced_mode < 0 && e->forced_path != 0) { // tiles (any width, any alignment); the run-shaped kernel serves 4 channels
+        CoefTileArgs t;
+        t.g = e->g;
+        t.rgb = d_rgb;
+        t.tab = e->d_tab;
+        t.out = d_coeffs;
+        t.n_frames = n_frames;
+        t.tile_cols = (e->g.n_strips + kTileStrips - 1) / kTileStrips;
+        t.tile_rows = (e->g.n_mbrows + kTileMbRows - 1) / kTileMbRows;
+        t.tiles_per_frame = t.tile_cols * t.tile_rows;
+        t.region = (std::max<uint32_t>((uint32_t)M1V_TILE_RING * kTileSlot, (uint32_t)(kWave * kCoefStride * 4)) + 15u) & ~15u;
+        hipLaunchKernelGGL((k_coefficient_tiles<M1V_TILE_RING>), dim3((unsigned)((size_t)n_frames * t.tiles_per_frame)),
+                           dim3(kTileThreads), 3 * (size_t)t.region, (hipStream_t)stream, t);
+        HIP_TRY(hipGetLastError());
+        return M1V_OK;
+    }
     int bps = e->g.n_mbrows * 6;
     dim3 grid((bps + 255) / 256, e->g.n_strips, n_frames);
     if (fast_path(e, d_rgb))

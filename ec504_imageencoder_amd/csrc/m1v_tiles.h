@@ -148,6 +148,89 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
 #define M1V_TILE_WAVES_PER_EU 6
 #endif
 
+// The front half of a tile wave (shared by k_encode_tiles and k_coefficient_tiles): brings the wave's 64 blocks in through
+// its LDS ring and leaves the 64 row-pass outputs of the lane's block in `rows`.  `ring` = LDS byte address of the wave's
+// region; wave 0, 1 = luma, wave 2 = chroma (see the head of this file); `first` / `meanwhile`: see below.
+template <int R, typename First, typename Meanwhile>
+__device__ __forceinline__ void tile_pixel_rows(const Geometry &g, const uint8_t *fbase, uint32_t ring, int wave, int lane, int s0,
+                                                int m0, int strips_here, int comp, First first, Meanwhile meanwhile,
+                                                RowStore<M1V_TILE_KEEP> &rows) {
+    const bool chroma = wave == 2;
+    // ---- the lane's share of the wave's DMA.  One row-step = TWO 1-KiB LDS-DMA instructions into a 2-KiB ring slot, the
+    //      same for the luma waves and the chroma wave (no branch, no EXEC mask, one vmcnt count):
+    //        luma    units 0..63 | units 64..95 (lanes 32..63 repeat them into the slot's unused last 512 bytes)
+    //        chroma  macroblock rows 0, 1 (2 x 192 bytes, lanes 0..23; the others repeat) | rows 2, 3, at +1024
+    //      Pieces outside the picture region (last tile column / row) re-read bytes of the last strip / macroblock row;
+    //      the lanes that own those blocks are not `valid`. ----
+    uint32_t pitch;          // bytes from row i to row i + 1 of a block
+    uint32_t voff_a, voff_b; // this lane's 16 bytes of row 0 (first / second instruction): byte offset from the frame base
+    uint32_t lane_row;       // LDS address of the lane's 24 bytes inside slot 0
+    if (!chroma) {
+        pitch = (uint32_t)g.W * 3u;
+        const uint32_t vw = (uint32_t)strips_here * 48u;
+        auto off = [&](uint32_t L) { // L-th 16-byte unit of the 1536-byte row-step: piece = picture row, `within` inside its 384 bytes
+            const uint32_t piece = L / 24u, within = min((L - piece * 24u) * 16u, vw - 16u);
+            const uint32_t mb = (uint32_t)min(m0 + 2 * wave + (int)(piece >> 1), g.n_mbrows - 1);
+            return ((mb * 16u + (piece & 1u) * 8u) * (uint32_t)g.W + (uint32_t)s0 * 16u) * 3u + within;
+        };
+        voff_a = off((uint32_t)lane);
+        voff_b = off(64u + (uint32_t)(lane & 31));
+        lane_row = ring + (uint32_t)lane * 24u;
+    } else {
+        pitch = (uint32_t)g.half_w * 3u;
+        const uint32_t vw = (uint32_t)strips_here * 24u;
+        // (an odd number of strips ends in the middle of a 16-byte unit: that unit is still fetched whole — up to 8 bytes
+        //  past the tile's last strip, still inside the first quarter of the frame, where all chroma sources lie)
+        const uint32_t L = (uint32_t)lane % 24u, piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
+        auto off = [&](uint32_t mbrow) {
+            const uint32_t mb = (uint32_t)min(m0 + (int)mbrow, g.n_mbrows - 1);
+            return ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
+        };
+        voff_a = off(piece);
+        voff_b = off(2u + piece);
+        const uint32_t mrow = ((uint32_t)lane >> 3) & 3u;
+        lane_row = ring + (mrow >> 1) * 1024u + (mrow & 1u) * 192u + ((uint32_t)lane & 7u) * 24u;
+    }
+    constexpr uint32_t kSlot = 2048;
+    auto issue_row = [&](int r) { // row-step r -> slot r % R.  M0 (the LDS destination) is set once: the second instruction's
+                                  // offset:1024 moves its LDS address AND its source address, so its base is 1024 lower
+        const uint8_t *sb = fbase + (size_t)r * pitch;
+        const uint32_t dst = ring + (uint32_t)(r % R) * kSlot;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_a), "v"(voff_b), "s"(dst), "s"(sb), "s"(sb - 1024));
+    };
+
+    // ---- everything this wave needs from memory is requested up front: what the caller adds (older in the vmcnt queue than
+    //      the rows), then R row-steps; the caller's other prologue work runs while they travel ----
+    first();
+#pragma unroll
+    for (int r = 0; r < R; r++) issue_row(r);
+    meanwhile();
+
+    // ---- rows out of the ring as they land, the freed slot refilled with row i + R ----
+    const CompCoefF kf = comp_coef_f(comp);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int newest = (i - 1 + R < 7) ? (i - 1 + R) : 7; // newest row-step requested so far
+        const int behind = newest - i;                         // row-steps that may still be in flight: two instructions each
+        if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<2>(); else if (behind == 2) wait_vm<4>();
+        else if (behind == 3) wait_vm<6>(); else if (behind == 4) wait_vm<8>(); else if (behind == 5) wait_vm<10>();
+        else if (behind == 6) wait_vm<12>(); else wait_vm<14>();
+        const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * kSlot);
+        if (i + R < 8) issue_row(i + R);
+        float px[8];
+        convert_row<3, M1V_TILE_LEAN>(v, kf, px);
+        float ro[8];
+        m1vf::fdct_row_f<float>(px, ro);
+        rows.put(i, ro);
+    }
+}
+
+
 template <bool STAGE8, int R>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(M1V_TILE_WAVES_PER_EU, M1V_TILE_WAVES_PER_EU)))
 void k_encode_tiles(TileArgs a) {
@@ -191,87 +274,24 @@ void k_encode_tiles(TileArgs a) {
         comp = blk_ < 4 ? 0 : blk_ - 3;
     }
 
-    // ---- the lane's share of the wave's DMA.  One row-step = TWO 1-KiB LDS-DMA instructions into a 2-KiB ring slot, the
-    //      same for the luma waves and the chroma wave (no branch, no EXEC mask, one vmcnt count):
-    //        luma    units 0..63 | units 64..95 (lanes 32..63 repeat them into the slot's unused last 512 bytes)
-    //        chroma  macroblock rows 0, 1 (2 x 192 bytes, lanes 0..23; the others repeat) | rows 2, 3, at +1024
-    //      Pieces outside the picture region (last tile column / row) re-read bytes of the last strip / macroblock row;
-    //      the lanes that own those blocks are not `valid`. ----
-    uint32_t pitch;          // bytes from row i to row i + 1 of a block
-    uint32_t voff_a, voff_b; // this lane's 16 bytes of row 0 (first / second instruction): byte offset from the frame base
-    uint32_t lane_row;       // LDS address of the lane's 24 bytes inside slot 0
-    const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
-    if (!chroma) {
-        pitch = (uint32_t)g.W * 3u;
-        const uint32_t vw = (uint32_t)strips_here * 48u;
-        auto off = [&](uint32_t L) { // L-th 16-byte unit of the 1536-byte row-step: piece = picture row, `within` inside its 384 bytes
-            const uint32_t piece = L / 24u, within = min((L - piece * 24u) * 16u, vw - 16u);
-            const uint32_t mb = (uint32_t)min(m0 + 2 * wave + (int)(piece >> 1), g.n_mbrows - 1);
-            return ((mb * 16u + (piece & 1u) * 8u) * (uint32_t)g.W + (uint32_t)s0 * 16u) * 3u + within;
-        };
-        voff_a = off((uint32_t)lane);
-        voff_b = off(64u + (uint32_t)(lane & 31));
-        lane_row = ring + (uint32_t)lane * 24u;
-    } else {
-        pitch = (uint32_t)g.half_w * 3u;
-        const uint32_t vw = (uint32_t)strips_here * 24u;
-        // (an odd number of strips ends in the middle of a 16-byte unit: that unit is still fetched whole — up to 8 bytes
-        //  past the tile's last strip, still inside the first quarter of the frame, where all chroma sources lie)
-        const uint32_t L = (uint32_t)lane % 24u, piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
-        auto off = [&](uint32_t mbrow) {
-            const uint32_t mb = (uint32_t)min(m0 + (int)mbrow, g.n_mbrows - 1);
-            return ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
-        };
-        voff_a = off(piece);
-        voff_b = off(2u + piece);
-        const uint32_t mrow = ((uint32_t)lane >> 3) & 3u;
-        lane_row = ring + (mrow >> 1) * 1024u + (mrow & 1u) * 192u + ((uint32_t)lane & 7u) * 24u;
-    }
-    constexpr uint32_t kSlot = 2048;
-    auto issue_row = [&](int r) { // row-step r -> slot r % R.  M0 (the LDS destination) is set once: the second instruction's
-                                  // offset:1024 moves its LDS address AND its source address, so its base is 1024 lower
-        const uint8_t *sb = fbase + (size_t)r * pitch;
-        const uint32_t dst = ring + (uint32_t)(r % R) * kSlot;
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff_a), "v"(voff_b), "s"(dst), "s"(sb), "s"(sb - 1024));
-    };
-
-    // ---- everything this wave needs from memory, requested up front: its own copy of the VLC table (a wave reads only its
-    //      own copy, so the waves of a tile do not meet before the bit counts are exchanged), then R row-steps ----
+    // ---- pixel stage (tile_pixel_rows): the wave's own copy of the VLC table is requested first (a wave reads only its own
+    //      copy, so the waves of a tile do not meet before the bit counts are exchanged), the image is cleared while the
+    //      first rows travel (it is first touched in pass 2, behind the barrier of the bit counts) ----
     TSTAMP_INIT();
-#pragma unroll
-    for (int q = 0; q < kVlcWords / kWave; q++)
-        dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kVlcWords + q * kWave) * 4u, a.tab->vlc + q * kWave);
-#pragma unroll
-    for (int r = 0; r < R; r++) issue_row(r);
-    // (the image is first touched in pass 2, behind the barrier of the bit counts)
-    for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
-    TSTAMP(0);
-    TSTAMP(1);
-
-    // ---- pixel stage: rows out of the ring as they land, the freed slot refilled with row i + R ----
-    const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
-    const CompCoefF kf = comp_coef_f(comp);
+    const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
     RowStore<M1V_TILE_KEEP> rows;
+    tile_pixel_rows<R>(
+        g, fbase, ring, wave, lane, s0, m0, strips_here, comp,
+        [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int newest = (i - 1 + R < 7) ? (i - 1 + R) : 7; // newest row-step requested so far
-        const int behind = newest - i;                         // row-steps that may still be in flight: two instructions each
-        if (behind == 0) wait_vm<0>(); else if (behind == 1) wait_vm<2>(); else if (behind == 2) wait_vm<4>();
-        else if (behind == 3) wait_vm<6>(); else if (behind == 4) wait_vm<8>(); else if (behind == 5) wait_vm<10>();
-        else if (behind == 6) wait_vm<12>(); else wait_vm<14>();
-        const Row24 v = ring_read24(lane_row + (uint32_t)(i % R) * kSlot);
-        if (i + R < 8) issue_row(i + R);
-        float px[8];
-        convert_row<3, M1V_TILE_LEAN>(v, kf, px);
-        float ro[8];
-        m1vf::fdct_row_f<float>(px, ro);
-        rows.put(i, ro);
-    }
+            for (int q = 0; q < kVlcWords / kWave; q++)
+                dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kVlcWords + q * kWave) * 4u, a.tab->vlc + q * kWave);
+        },
+        [&]() {
+            for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
+        },
+        rows);
+    const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
     // The lane's place in the tile, derived again behind the pixel stage (from an opaque copy of the lane id: five values
     // less to carry through the stage, whose register budget decides the waves per SIMD)
     int j, m, blk;
@@ -382,6 +402,78 @@ void k_encode_tiles(TileArgs a) {
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
     TSTAMP(9);
     TSTAMP_FLUSH();
+}
+
+// ---- BASELINE config 2 on tiles: FDCT + quantise + zigzag only (image_processing.c:192-381), int16 levels out ----------
+// The same front half as k_encode_tiles; the 64 levels of a block are staged as int16 at their zigzag index (block stride 34
+// words: 8-byte aligned, two lanes per bank), and the tile's eight strip segments (24 consecutive blocks = 3 KiB of the
+// output each) leave as whole 128-byte lines: 8 bytes per lane and store instruction, consecutive lanes consecutive bytes.
+struct CoefTileArgs {
+    Geometry g;
+    const uint8_t *rgb;
+    const Tables *tab;
+    int16_t *out; // [frame][strip][macroblock][Y0 Y1 Y2 Y3 Cb Cr][64]
+    int n_frames, tile_cols, tile_rows, tiles_per_frame;
+    uint32_t region; // LDS bytes of a wave's ring / staging region
+};
+constexpr int kCoefStride = 34; // words per staged block
+
+template <int R>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(M1V_TILE_WAVES_PER_EU, M1V_TILE_WAVES_PER_EU)))
+void k_coefficient_tiles(CoefTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const Geometry &g = a.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    int frame, tile;
+    frame_strip_of(blockIdx.x, a.n_frames, a.tiles_per_frame, frame, tile);
+    const int tr = tile / a.tile_cols, tc = tile - tr * a.tile_cols;
+    const int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
+    const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+    const int strips_here = min(kTileStrips, g.n_strips - s0), mrows_here = min(kTileMbRows, g.n_mbrows - m0);
+    const int comp = wave == 2 ? 1 + (lane >> 5) : 0;
+
+    RowStore<M1V_TILE_KEEP> rows;
+    tile_pixel_rows<R>(g, fbase, lds0 + (uint32_t)wave * a.region, wave, lane, s0, m0, strips_here, comp, [] {}, [] {}, rows);
+
+    // column pass + quantise; level of zigzag position p -> int16 p of the lane's staged block (the ring is drained: its bytes are reused)
+    const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
+    uint32_t lds_addr = lds0 + (uint32_t)wave * a.region + (uint32_t)lane * (kCoefStride * 4u);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float c[8];
+        m1vf::fdct_col_f<float>(rows.get(0, i), rows.get(1, i), rows.get(2, i), rows.get(3, i), rows.get(4, i), rows.get(5, i),
+                                rows.get(6, i), rows.get(7, i), c, i == 0 ? RowStore<M1V_TILE_KEEP>::kBias0 : 0.0f);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = quant(c[u], rq_t[i * 8 + u]);
+            asm("ds_write_b16 %0, %1 offset:%2" : "+v"(lds_addr) : "v"(q), "n"(2 * scan_pos(u * 8 + i)));
+        }
+    }
+    // every wave's blocks staged (the barrier takes the address register the stores are chained through)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::"v"(lds_addr) : "memory");
+
+    // store: unit = 16 bytes (two 8-byte LDS reads: the staged blocks are 8-byte aligned); a strip segment = 24 blocks x 8
+    // units, in emission order (macroblock row, then Y0 Y1 Y2 Y3 Cb Cr)
+    const int bps = g.n_mbrows * 6;
+    const unsigned char *lds_bytes = reinterpret_cast<const unsigned char *>(lds);
+    const int units_valid = mrows_here * 6 * 8;
+#pragma unroll
+    for (int t = 0; t < kTileStrips * kTileSegBlocks * 8 / kTileThreads; t++) {
+        const int u = tid + t * kTileThreads;
+        const int j = u / (kTileSegBlocks * 8), within = u - j * (kTileSegBlocks * 8);
+        if (j >= strips_here || within >= units_valid) continue;
+        const int b = within >> 3, part = within & 7, m = b / 6, blk = b - m * 6;
+        // who staged block (j, m, blk): see the lane order of the luma / chroma waves at the head of this file
+        const int w_src = blk < 4 ? (m >> 1) : 2;
+        const int l_src = blk < 4 ? (m & 1) * 32 + (blk >> 1) * 16 + j * 2 + (blk & 1) : (blk - 4) * 32 + m * 8 + j;
+        const unsigned char *from = lds_bytes + (size_t)w_src * a.region + (size_t)l_src * (kCoefStride * 4) + part * 16;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(from), hi = *reinterpret_cast<const uint2 *>(from + 8);
+        int16_t *o = a.out + (((size_t)frame * g.n_strips + (size_t)(s0 + j)) * bps + (size_t)m0 * 6) * 64;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(o) + (size_t)within * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
 }
 
 // ---- layout and gather for tiles: a strip is the concatenation of its tile_rows segments ---------------------------

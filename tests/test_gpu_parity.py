@@ -207,13 +207,24 @@ def test_subsample(torch_cuda, orc):
 @pytest.mark.parametrize("W,H,mode", [(1920, 1080, "full"), (1920, 1080, "strict"), (352, 288, "full"),
                                       (360, 250, "full"), (100, 150, "strict"), (3840, 2160, "full")])
 def test_config2_coefficients_bit_exact(torch_cuda, orc, W, H, mode):
-    """BASELINE config 2: DCT+quant+zigzag only, every block coefficient vs the oracle."""
-    enc = _enc(W, H, mode=mode, max_frames=1)
-    rgb = enc.synth(1, seed=2024)
-    got = enc.coefficients(rgb).cpu().numpy().astype(np.int32)[0]
-    want = orc.frame_coefficients(rgb.cpu().numpy()[0], W, H, 12, _omode(orc, mode))
-    assert got.shape == want.shape and np.array_equal(got, want)
-    enc.close()
+    """BASELINE config 2: DCT+quant+zigzag only, every block coefficient vs the oracle; through the tile form of the
+    kernel (3-channel default: LDS-DMA tiles, whole-line stores) and through the run-shaped one (forced; serves 4 channels),
+    also from a buffer that starts at an odd address, and at a quality whose levels need all 16 bits of the output."""
+    torch = torch_cuda
+    for qf, shift, path in ((12, 0, "auto"), (12, 0, "runs"), (100, 1, "auto")):
+        enc = _enc(W, H, qf, mode=mode, max_frames=2)
+        if path != "auto":
+            enc.debug_set_path(path)
+        src = enc.synth(2, seed=2024)
+        flat = torch.empty(src.numel() + 16, dtype=torch.uint8, device="cuda")
+        rgb = flat[shift:shift + src.numel()].view(src.shape)
+        rgb.copy_(src)
+        got = enc.coefficients(rgb).cpu().numpy().astype(np.int32)
+        host = src.cpu().numpy()
+        for f in range(2):
+            want = orc.frame_coefficients(host[f], W, H, qf, _omode(orc, mode))
+            assert got[f].shape == want.shape and np.array_equal(got[f], want), (qf, shift, path, f)
+        enc.close()
 
 
 @pytest.mark.parametrize("fn", G.E2E_FILES)
