@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--gather", default="xgmi", choices=["xgmi", "host"],
                     help="N>1: how the per-rank bitstreams reach one place.  xgmi = grouped send/recv to rank 0 (RCCL); "
                          "host = every rank copies its blob into its slice of one pinned host buffer shared by the ranks")
+    ap.add_argument("--deliver", default="host", choices=["none", "host"],
+                    help="N=1: after the headline run, time the same steps with every batch's frame records delivered to pinned host "
+                         "memory (device-to-host copy of batch k on a side stream under the encode of batch k+1); reported as the "
+                         "`host_delivery` sub-record, never as `value`")
     ap.add_argument("--path", default="auto", choices=["auto", "tiles", "runs"],
                     help="which encode kernel serves the batches (include/mpeg1_hip.h, m1v_debug_set_path); auto = the library's choice")
     ap.add_argument("--cli", action="store_true",
@@ -391,6 +395,28 @@ def main():
             head = out[:min(out.numel(), 4 * (W * H // 2))].cpu().numpy().tobytes()   # first frame records of rank 0
             line["cpu_baseline"] = cpu_baseline(W, H, qf, seed, gpu_head=head)
             assert line["cpu_baseline"].get("gpu_output_matches_oracle", True), "GPU output differs from the oracle"
+        if world == 1 and args.deliver == "host":
+            # the path's product is a host bitstream (north_star; the reference fwrites it, encoder.h:445): input resident,
+            # records of batch k copied to one of two pinned buffers while batch k+1 encodes
+            from ec504_imageencoder_amd.delivery import HostDelivery
+            hd = HostDelivery(enc, n, capacity=outs[0].numel())
+            for _ in range(max(4, args.warmup // 4)):
+                hd.step(rgb, first)
+            hd.fence()
+            hd.bytes_delivered = 0
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                hd.step(rgb, first)
+            hd.fence()
+            dt = time.perf_counter() - t0
+            same = bool(torch.equal(hd.result(), outs[(step_no - 1) % len(outs)][:total_bytes].cpu()))
+            line["host_delivery"] = {"value": round(n * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+                                     "pcie_gb_per_s": round(hd.bytes_delivered / dt / 1e9, 2), "bytes_per_step": hd.bytes_delivered // args.steps,
+                                     "holds_device_resident_rate": round(n * args.steps / dt / fps, 4),
+                                     "delivered_equals_device_output": same,
+                                     "note": "input resident in HBM; frame records of batch k -> pinned host memory on a side stream while batch "
+                                             "k+1 encodes (ec504_imageencoder_amd/delivery.py); one host wait per step on 16 pinned bytes"}
+            assert same, "delivered bytes differ from the device-resident output"
         if world == 1 and args.host_path:
             # PCIe-inclusive rate of the host-buffer entry point (never the headline value)
             m = min(n, 64)

@@ -167,6 +167,27 @@ def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path)
     enc.close()
 
 
+def test_host_delivery_overlapped_with_the_next_encode(torch_cuda, orc):
+    """HostDelivery: batch k's records travel to pinned host memory on a side stream while batch k+1 encodes.  Five
+    batches of DIFFERENT frames through two buffers: what arrives on the host is the oracle's stream, every time."""
+    from ec504_imageencoder_amd.delivery import HostDelivery
+    W, H, n = 352, 288, 3
+    enc = _enc(W, H, max_frames=n)
+    hd = HostDelivery(enc, n)
+    batches = [enc.synth(n, seed=70 + k) for k in range(5)]
+    wants = [orc.encode_frames(b.cpu().numpy(), n, W, H, 100 * k, 12, orc.MODE_FULL)[0] for k, b in enumerate(batches)]
+    got = []
+    for k, b in enumerate(batches):
+        hd.step(b, 100 * k)
+        if hd.last is not None and len(got) < k:      # batch k-1 was delivered behind the encode of batch k
+            hd.delivered[hd.last[0]].synchronize()
+            got.append(bytes(hd.result().numpy()))
+    hd.fence()
+    got.append(bytes(hd.result().numpy()))
+    assert got == wants
+    enc.close()
+
+
 def test_path_is_picked_by_geometry_and_alignment(torch_cuda, orc):
     """Aligned 3-channel pictures (width % 8 == 0, 4-byte aligned buffer) take the run kernel, every other 3-channel
     input the tile kernel; an encoder that meets a misaligned buffer switches to tiles for good.  Same bytes either way."""
