@@ -28,7 +28,7 @@ MPEG1_HIP_SYMBOLS = [
 
 
 ENCODER_H_SYMBOLS = ["mpeg_encode_procedure", "mpeg_encode_procedure_region", "encoder_set_image_loader",
-                     "encoder_set_host_threads"]
+                     "encoder_set_host_threads", "encoder_release_cache"]
 
 
 class EncoderLibraryMissing(RuntimeError):

@@ -12,6 +12,11 @@
  *   EC504_ENCODE_REGION=full|strict   region used by mpeg_encode_procedure()  (default strict)
  *   EC504_WRITE_BIT=0                 skip the image_<k>.bit side files         (default: write them)
  *   EC504_DEVICE=<n>                  GPU index                                (default 0)
+ *   EC504_DEVICES=<a,b,...>           one GPU encoder per entry, chunk c goes to entry c mod N; the same index may
+ *                                     appear more than once (default "<d>,<d>", d = EC504_DEVICE: two encoders on one
+ *                                     GPU, so that one chunk's upload runs under the other's kernels and downloads)
+ *   EC504_KEEP_ENCODER=0              do not keep the GPU encoders and pinned buffers for the next call (default: keep;
+ *                                     encoder_release_cache() frees them)
  *   EC504_BATCH=<n>                   frames per device batch                  (default 64)
  *   EC504_HOST_THREADS=<n>            decode / staging / .bit-writer threads   (default: online CPUs, <= 64;
  *                                     1 = everything on the calling thread, as the reference)
@@ -191,10 +196,8 @@ static void decode_task(void *ctx, int i) { /* encoder.h:162 */
     im->data = g_load(j->path[i], &im->width, &im->height, &im->channels, 0);
 }
 
-static void warm_task(void *ctx, int i) { /* start the GPU runtime while the first files decode */
-    (void)ctx;
-    (void)i;
-    (void)m1v_warm_up(env_int("EC504_DEVICE", 0));
+static void warm_task(void *ctx, int i) { /* start the GPU runtime (device i of the list) while the first files decode */
+    (void)m1v_warm_up(((const int *)ctx)[i]);
 }
 
 typedef struct {
@@ -237,6 +240,94 @@ static void remove_bit_file(const char *folder, int k) {
     char path[256];
     snprintf(path, sizeof path, "%s/image_%d.bit", folder, k);
     (void)remove(path);
+}
+
+/* ---- several GPU encoders in flight (SURVEY 8e inside the C library) -------------------------------
+ * A LANE is one m1v_encoder with its own pinned output buffer.  Chunk c is encoded by lane c mod N as a pool task, so N
+ * chunks are on GPUs at once — on N different GPUs (frames are independent given their global index: the chunk's first
+ * frame index travels with it), or twice on the same GPU, where the upload of one chunk overlaps the kernels and the
+ * downloads of the other.  The caller retires chunks in order and appends their frame records to the video: the file is
+ * the gather. */
+enum { MAX_LANES = 16 };
+
+typedef struct {
+    m1v_encoder *enc;
+    uint8_t *out;      /* pinned */
+    size_t out_cap;
+    uint64_t *sizes;
+    /* the chunk in flight */
+    const uint8_t *in;
+    uint8_t *planes;
+    int n, first;
+    long total;        /* result of m1v_encode_planes_host */
+    char err[256];     /* m1v_last_error() of the thread that ran the task (it is per thread) */
+} Lane;
+
+static void gpu_task(void *ctx, int i) {
+    Lane *l = (Lane *)ctx;
+    (void)i;
+    l->total = m1v_encode_planes_host(l->enc, l->in, l->n, l->first, l->out, l->out_cap, l->sizes, l->planes);
+    if (l->total < 0) snprintf(l->err, sizeof l->err, "%s", m1v_last_error());
+}
+
+/* Everything a call needs on the device side, kept between calls when the next call asks for the same thing: creating
+ * the encoders and page-locking ~100 MB per slot costs more than encoding a small folder. */
+typedef struct {
+    int valid;
+    int devices[MAX_LANES], n_lanes, W, H, C, qf, region, batch, write_bit, n_slots;
+    Lane lane[MAX_LANES];
+    uint8_t *batch_in[MAX_LANES + 1], *planes[MAX_LANES + 1];
+} GpuContext;
+
+static GpuContext g_cache;
+static pthread_mutex_t g_cache_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void context_free(GpuContext *c) {
+    for (int l = 0; l < c->n_lanes; l++) {
+        m1v_destroy(c->lane[l].enc);
+        m1v_free_host(c->lane[l].out);
+        free(c->lane[l].sizes);
+    }
+    for (int s = 0; s < c->n_slots; s++) {
+        m1v_free_host(c->batch_in[s]);
+        m1v_free_host(c->planes[s]);
+    }
+    memset(c, 0, sizeof *c);
+}
+
+void encoder_release_cache(void) {
+    pthread_mutex_lock(&g_cache_mu);
+    if (g_cache.valid) context_free(&g_cache);
+    pthread_mutex_unlock(&g_cache_mu);
+}
+
+static int context_matches(const GpuContext *c, const GpuContext *want) {
+    if (!c->valid || c->n_lanes != want->n_lanes || c->W != want->W || c->H != want->H || c->C != want->C || c->qf != want->qf ||
+        c->region != want->region || c->batch < want->batch || c->write_bit < want->write_bit || c->n_slots < want->n_slots)
+        return 0;
+    for (int l = 0; l < c->n_lanes; l++)
+        if (c->devices[l] != want->devices[l]) return 0;
+    return 1;
+}
+
+/* EC504_DEVICES, or two lanes on EC504_DEVICE */
+static int parse_devices(int devices[MAX_LANES]) {
+    const char *v = getenv("EC504_DEVICES");
+    int n = 0;
+    if (v && *v) {
+        while (*v && n < MAX_LANES) {
+            char *end;
+            long d = strtol(v, &end, 10);
+            if (end == v) break;
+            devices[n++] = (int)d;
+            v = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (n == 0) {
+        devices[0] = devices[1] = env_int("EC504_DEVICE", 0);
+        n = 2;
+    }
+    return n;
 }
 
 static double now_s(void) {
@@ -329,18 +420,20 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     Pool pool;
     pool_open(&pool, host_threads());
     ImageList imgs = {NULL, 0, 0};
-    m1v_encoder *enc = NULL;
-    uint8_t *batch_in[2] = {NULL, NULL}, *planes[2] = {NULL, NULL}, *batch_out = NULL;
-    uint64_t *sizes = NULL;
-    Group staged[2], written[2], decoded[RING], warm;
+    GpuContext cx;
+    memset(&cx, 0, sizeof cx);
+    Group staged[MAX_LANES + 1], written[MAX_LANES + 1], on_gpu[MAX_LANES], decoded[RING], warm;
     DecodeJob dj[RING];
-    StageJob sj[2];
-    BitJob bj[2];
+    StageJob sj[MAX_LANES + 1];
+    BitJob bj[MAX_LANES + 1];
     memset(staged, 0, sizeof staged);
     memset(written, 0, sizeof written);
+    memset(on_gpu, 0, sizeof on_gpu);
     memset(decoded, 0, sizeof decoded);
     memset(&warm, 0, sizeof warm);
-    int frames_done = 0; /* frames encoded so far = global index of the next frame = .bit files written */
+    int frames_done = 0; /* frames retired so far = frame records in the video = .bit files written (or being written) */
+    int *chunk_frames = NULL, *chunk_first = NULL; /* loaded frames of a chunk, global index of its first frame */
+    int warm_devices[MAX_LANES], n_warm = 0;
 
     imgs.v = (Image *)calloc((size_t)(n_paths ? n_paths : 1), sizeof(Image));
     if (scan_failed || !imgs.v) {
@@ -348,7 +441,13 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
         goto done;
     }
     imgs.n = imgs.cap = n_paths;
-    if (n_paths > 0 && pool.n_threads > 0) group_start(&pool, &warm, warm_task, NULL, 1); /* GPU runtime start-up */
+    cx.n_lanes = parse_devices(cx.devices);
+    for (int l = 0; l < cx.n_lanes; l++) { /* the distinct devices: their runtimes start while the first files decode */
+        int seen = 0;
+        for (int k = 0; k < n_warm; k++) seen |= warm_devices[k] == cx.devices[l];
+        if (!seen) warm_devices[n_warm++] = cx.devices[l];
+    }
+    if (n_paths > 0 && pool.n_threads > 0) group_start(&pool, &warm, warm_task, warm_devices, n_warm);
 
     /* head: the first file that decodes fixes the geometry (and with it the batch size) */
     int head = 0;
@@ -370,9 +469,12 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     if (batch < 1) batch = 1;
     if (batch > n_paths - head) batch = n_paths - head;
     const int n_chunks = (n_paths - head + batch - 1) / batch;
+    if (cx.n_lanes > n_chunks) cx.n_lanes = n_chunks; /* no more encoders than chunks */
+    const int N = cx.n_lanes;
     /* enough chunks of decoding in flight to keep every thread busy (1.5 files per thread), 2..15 */
     int look = (3 * (pool.n_threads + 1) / 2 + batch - 1) / batch;
-    look = look < 2 ? 2 : look > RING - 1 ? RING - 1 : look;
+    look = look < N + 1 ? N + 1 : look;
+    look = look > RING - 1 ? RING - 1 : look;
 #define CHUNK_FIRST(c) (head + (c) * batch)
 #define CHUNK_FILES(c) (n_paths - CHUNK_FIRST(c) < batch ? n_paths - CHUNK_FIRST(c) : batch)
     int next_decode = 0;
@@ -382,52 +484,78 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     }
     t_phase[1] = now_s();
 
-    /* GPU encoder and pinned buffers, on this thread, while the pool decodes */
+    /* GPU encoders and pinned buffers, on this thread, while the pool decodes: taken over from the previous call when it
+     * asked for the same thing */
     if (C < 3) { /* image_processing.c:69-73 prints this and the reference then crashes */
         printf("Error: Image does not have correct color channels for RBG to YCbCr conversion.\n");
         goto done;
     }
     const int write_bit = env_int("EC504_WRITE_BIT", 1);
-    if (m1v_create(&enc, env_int("EC504_DEVICE", 0), W, H, C, quality_factor, region ? M1V_MODE_FULL : M1V_MODE_STRICT,
-                   batch) != M1V_OK) {
-        printf("Error: cannot set up the GPU encoder: %s\n", m1v_last_error());
-        enc = NULL;
-        goto done;
+    cx.W = W, cx.H = H, cx.C = C, cx.qf = quality_factor, cx.region = region, cx.batch = batch, cx.write_bit = write_bit;
+    cx.n_slots = n_chunks > N ? N + 1 : N; /* chunks on the lanes + the one being staged */
+    chunk_frames = (int *)calloc((size_t)n_chunks + 1, sizeof(int));
+    chunk_first = (int *)calloc((size_t)n_chunks + 1, sizeof(int));
+    int alloc_ok = chunk_frames && chunk_first;
+    pthread_mutex_lock(&g_cache_mu);
+    if (context_matches(&g_cache, &cx)) {
+        cx = g_cache; /* (batch, slots and planes may be larger than asked for) */
+        memset(&g_cache, 0, sizeof g_cache);
     }
-    t_created = now_s();
-    const size_t bound = m1v_frame_bound(enc);
-    /* pinned staging (copies to and from the GPU then run at the PCIe rate), two slots.  The output buffer
-     * starts at 1/16 of the worst case (white noise needs about 1/46 of it, pictures built to be expensive
-     * about 1/11) and grows on demand (see below). */
-    size_t out_cap = bound * ((size_t)batch + 1) / 16;
-    batch_out = (uint8_t *)m1v_alloc_host(out_cap);
-    sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
-    int alloc_ok = batch_out && sizes;
-    for (int s = 0; s < (n_chunks > 1 ? 2 : 1); s++) {
-        batch_in[s] = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
-        if (write_bit) planes[s] = (uint8_t *)m1v_alloc_host(frame_planes * (size_t)batch);
-        alloc_ok = alloc_ok && batch_in[s] && (!write_bit || planes[s]);
+    pthread_mutex_unlock(&g_cache_mu);
+    size_t bound = 0;
+    if (!cx.valid) {
+        for (int l = 0; l < N && alloc_ok; l++) {
+            if (m1v_create(&cx.lane[l].enc, cx.devices[l], W, H, C, quality_factor, region ? M1V_MODE_FULL : M1V_MODE_STRICT,
+                           batch) != M1V_OK) {
+                printf("Error: cannot set up the GPU encoder: %s\n", m1v_last_error());
+                cx.lane[l].enc = NULL;
+                alloc_ok = 0;
+                cx.valid = 1; /* so that what exists is freed */
+                goto done;
+            }
+        }
+        t_created = now_s();
+        bound = m1v_frame_bound(cx.lane[0].enc);
+        /* pinned staging (copies to and from the GPU then run at the PCIe rate).  A lane's output buffer starts at 1/16 of
+         * the worst case (white noise needs about 1/46 of it, pictures built to be expensive about 1/11) and grows on
+         * demand (see below). */
+        for (int l = 0; l < N; l++) {
+            cx.lane[l].out_cap = bound * ((size_t)batch + 1) / 16;
+            cx.lane[l].out = (uint8_t *)m1v_alloc_host(cx.lane[l].out_cap);
+            cx.lane[l].sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
+            alloc_ok = alloc_ok && cx.lane[l].out && cx.lane[l].sizes;
+        }
+        for (int s = 0; s < cx.n_slots; s++) {
+            cx.batch_in[s] = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
+            if (write_bit) cx.planes[s] = (uint8_t *)m1v_alloc_host(frame_planes * (size_t)batch);
+            alloc_ok = alloc_ok && cx.batch_in[s] && (!write_bit || cx.planes[s]);
+        }
+        cx.valid = 1;
+    } else {
+        t_created = now_s();
+        bound = m1v_frame_bound(cx.lane[0].enc);
     }
     if (!alloc_ok) {
         printf("Error: Memory allocation failed.\n");
         goto done;
     }
+    const int S = cx.n_slots;
     t_phase[2] = now_s();
 
-    int n_cur = 0, n_next = 0; /* loaded frames of the chunk on the GPU / of the one being staged */
-    for (int c = -1; c < n_chunks; c++) {
-        const int s = c & 1;
-        if (c >= 0) group_wait(&pool, &staged[s]);
+    /* Iteration c: chunk c+1 is joined from its decode and handed to the pool for staging; chunk c (staged) goes to its
+     * lane; chunk c-N+1 is retired: its records are appended to the video, its .bit files handed to the pool. */
+    for (int c = -1; c < n_chunks + N - 1; c++) {
+        if (c >= 0 && c < n_chunks) group_wait(&pool, &staged[c % S]);
         if (c >= 0 && next_decode < n_chunks) { /* keep `look` chunks of decoding ahead of the GPU */
             const int r = next_decode % RING; /* ring entry of a chunk <= c-1, joined at least one pass ago */
             dj[r] = (DecodeJob){paths + CHUNK_FIRST(next_decode), imgs.v + CHUNK_FIRST(next_decode)};
             group_start(&pool, &decoded[r], decode_task, &dj[r], CHUNK_FILES(next_decode));
             next_decode++;
         }
-        n_next = 0;
         if (c + 1 < n_chunks) { /* join chunk c+1's decode, check it, let the pool stage it */
-            const int first = CHUNK_FIRST(c + 1), files = CHUNK_FILES(c + 1);
+            const int first = CHUNK_FIRST(c + 1), files = CHUNK_FILES(c + 1), slot = (c + 1) % S;
             Image *v = imgs.v + first;
+            int n_next = 0;
             group_wait(&pool, &decoded[(c + 1) % RING]);
             for (int i = 0; i < files; i++) {
                 if (!v[i].data) {
@@ -445,33 +573,45 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
             }
             for (int i = n_next; i < files; i++) v[i].data = NULL;
             if (mismatch) goto done;
-            sj[1 - s] = (StageJob){v, batch_in[(c + 1) & 1], frame_in};
-            group_start(&pool, &staged[(c + 1) & 1], stage_task, &sj[1 - s], n_next);
+            chunk_frames[c + 1] = n_next;
+            chunk_first[c + 1] = c >= 0 ? chunk_first[c] + chunk_frames[c] : 0;
+            /* the slot's previous chunk (c+1-S) left its lane at least one pass ago; its .bit files may still be on their way */
+            group_wait(&pool, &written[slot]);
+            sj[slot] = (StageJob){v, cx.batch_in[slot], frame_in};
+            group_start(&pool, &staged[slot], stage_task, &sj[slot], n_next);
         }
-        if (c >= 0 && n_cur > 0) {
-            group_wait(&pool, &written[s]); /* planes[s] may still be on their way to disk (chunk c-2) */
-            long total = m1v_encode_planes_host(enc, batch_in[s], n_cur, frames_done, batch_out, out_cap, sizes,
-                                                write_bit ? planes[s] : NULL);
-            if (total == M1V_E_NOSPACE && out_cap < bound * (size_t)batch) { /* rare: grow to the worst case, redo */
-                m1v_free_host(batch_out);
-                out_cap = bound * (size_t)batch;
-                batch_out = (uint8_t *)m1v_alloc_host(out_cap);
-                total = batch_out ? m1v_encode_planes_host(enc, batch_in[s], n_cur, frames_done, batch_out, out_cap,
-                                                           sizes, write_bit ? planes[s] : NULL)
-                                  : M1V_E_HIP;
+        if (c >= 0 && c < n_chunks && chunk_frames[c] > 0) { /* chunk c onto its lane (free: its previous chunk, c-N, was retired one pass ago) */
+            Lane *l = &cx.lane[c % N];
+            l->in = cx.batch_in[c % S];
+            l->planes = write_bit ? cx.planes[c % S] : NULL;
+            l->n = chunk_frames[c];
+            l->first = chunk_first[c];
+            l->total = M1V_E_HIP;
+            group_start(&pool, &on_gpu[c % N], gpu_task, l, 1);
+        }
+        const int retire = c - N + 1;
+        if (retire >= 0 && retire < n_chunks && chunk_frames[retire] > 0) {
+            Lane *l = &cx.lane[retire % N];
+            const int slot = retire % S, n_cur = chunk_frames[retire];
+            group_wait(&pool, &on_gpu[retire % N]);
+            if (l->total == M1V_E_NOSPACE && l->out_cap < bound * (size_t)batch) { /* rare: grow to the worst case, redo */
+                m1v_free_host(l->out);
+                l->out_cap = bound * (size_t)batch;
+                l->out = (uint8_t *)m1v_alloc_host(l->out_cap);
+                l->total = M1V_E_HIP;
+                if (l->out) gpu_task(l, 0);
             }
-            if (total < 0) {
-                printf("Error: GPU encode failed: %s\n", m1v_last_error());
+            if (l->total < 0) {
+                printf("Error: GPU encode failed: %s\n", l->err);
                 goto done;
             }
-            fwrite(batch_out, 1, (size_t)total, fp);
-            if (write_bit) { /* encoder.h:461-465, written behind the next chunk */
-                bj[s] = (BitJob){bitstream_folder, planes[s], frames_done + 1, W, H};
-                group_start(&pool, &written[s], bit_task, &bj[s], n_cur);
+            fwrite(l->out, 1, (size_t)l->total, fp);
+            if (write_bit) { /* encoder.h:461-465, written behind the following chunks */
+                bj[slot] = (BitJob){bitstream_folder, cx.planes[slot], frames_done + 1, W, H};
+                group_start(&pool, &written[slot], bit_task, &bj[slot], n_cur);
             }
             frames_done += n_cur;
         }
-        n_cur = n_next;
     }
     printf("Image processing finished.\n");
     rc = 0;
@@ -480,7 +620,8 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
 done:
     group_wait(&pool, &warm); /* nothing may still reference what is freed below */
     for (int r = 0; r < RING; r++) group_wait(&pool, &decoded[r]);
-    for (int s = 0; s < 2; s++) {
+    for (int l = 0; l < MAX_LANES; l++) group_wait(&pool, &on_gpu[l]);
+    for (int s = 0; s <= MAX_LANES; s++) {
         group_wait(&pool, &staged[s]);
         group_wait(&pool, &written[s]);
     }
@@ -491,18 +632,25 @@ done:
     }
     t_phase[4] = now_s();
     if (timing && rc == 0)
-        fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d: first decode %.3f s, gpu encoder %.3f s, pinned "
-                        "buffers %.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
-                t_phase[1] - t_phase[0], t_created - t_phase[1], t_phase[2] - t_created, t_phase[3] - t_phase[2],
+        fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d, %d encoder(s): first decode %.3f s, gpu encoders %.3f s, "
+                        "pinned buffers %.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
+                cx.n_lanes, t_phase[1] - t_phase[0], t_created - t_phase[1], t_phase[2] - t_created, t_phase[3] - t_phase[2],
                 t_phase[4] - t_phase[3]);
     pool_close(&pool);
-    for (int s = 0; s < 2; s++) {
-        m1v_free_host(batch_in[s]);
-        m1v_free_host(planes[s]);
+    if (cx.valid) { /* keep the device side for the next call, or give it back */
+        int keep = rc == 0 && env_int("EC504_KEEP_ENCODER", 1);
+        for (int l = 0; keep && l < cx.n_lanes; l++) keep = cx.lane[l].enc && cx.lane[l].out && cx.lane[l].sizes;
+        pthread_mutex_lock(&g_cache_mu);
+        if (keep) {
+            if (g_cache.valid) context_free(&g_cache);
+            g_cache = cx;
+        } else {
+            context_free(&cx);
+        }
+        pthread_mutex_unlock(&g_cache_mu);
     }
-    m1v_free_host(batch_out);
-    free(sizes);
-    m1v_destroy(enc);
+    free(chunk_frames);
+    free(chunk_first);
     release_images(&imgs);
     for (int i = 0; i < n_paths; i++) free(paths[i]);
     free(paths);

@@ -67,6 +67,10 @@ void encoder_set_image_loader(encoder_image_load_fn load, encoder_image_free_fn 
  * The environment variable EC504_HOST_THREADS overrides it. */
 void encoder_set_host_threads(int n);
 
+/* mpeg_encode_procedure keeps its GPU encoders and pinned buffers for the next call with the same picture geometry,
+ * quality factor, region and device list (environment EC504_KEEP_ENCODER=0 turns that off).  This frees them. */
+void encoder_release_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,31 @@ def test_cli_end_to_end_vs_reference_binary(region, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_several_encoders_on_one_gpu_give_the_single_encoder_stream(devices, tmp_path):
+    """EC504_DEVICES (csrc/encoder_host.c): one encoder per list entry, chunk c on entry c mod N, the frame records
+    appended in order.  On this one-GPU box the same device is listed one, two and three times: 14 frames in chunks of 3
+    through the real library, twice in one process (the second call takes over the cached encoders), must equal the
+    reference binary's files.  Multi-GPU lists ("0,1,...") run the same code; they are unmeasured on hardware."""
+    if not (os.path.exists(CLI) and os.path.exists(REF_FULL)):
+        pytest.skip("prebuilt CLI / reference binaries not shipped")
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (160, 208, 3), dtype=np.uint8) for _ in range(14)]
+    d = tmp_path
+    _jpegs(str(d / "images"), frames)
+    (d / "out").mkdir()
+    (d / "ref").mkdir()
+    assert _run(REF_FULL, str(d), "images/", "ref", "ref/v.mpeg", "12") == 0
+    env = {"EC504_DEVICES": devices, "EC504_BATCH": "3", "EC504_CLI_REPEAT": "2"}
+    assert _run(CLI, str(d), "images/", "out", "out/v.mpeg", "12", "full", env=env) == 0
+    want = (d / "ref" / "v.mpeg").read_bytes()
+    assert (d / "out" / "v.mpeg").read_bytes() == want and (d / "out" / "v.mpeg.2").read_bytes() == want
+    for k in range(1, 15):
+        assert (d / "out" / f"image_{k}.bit").read_bytes() == (d / "ref" / f"image_{k}.bit").read_bytes()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("region,batch", [("full", 3), ("strict", 64)])
 def test_host_driver_with_a_custom_loader(region, batch, tmp_path, orc, monkeypatch):
     """The C host driver (csrc/encoder_host.c) end to end on the GPU without stb: files named *.jpg hold raw pixels,

@@ -80,6 +80,27 @@ def test_threaded_host_driver_matches_reference_binary(builds, san, region, thre
     assert not (tmp_path / "out" / f"image_{n + 1}.bit").exists()
 
 
+@pytest.mark.parametrize("san,devices,threads,batch", [("thread", "0", 4, 2), ("thread", "0,0,0", 6, 1), ("address", "0,1", 3, 3),
+                                                       ("thread", "", 1, 2), ("address", "0,0,0,0", 5, 64)])
+def test_several_encoders_in_flight_and_kept_between_calls(builds, san, devices, threads, batch, tmp_path):
+    """EC504_DEVICES: one encoder per list entry, chunk c on entry c mod N, N chunks on GPUs at once, retired in order (the
+    stand-in ignores the device index, so "0,1" runs here too).  Same bytes as the reference binary for every lane count —
+    one lane, the default two on one device, more lanes than chunks — and for a SECOND call in the same process, which takes
+    over the encoders and pinned buffers of the first (EC504_CLI_REPEAT)."""
+    n = _folder(tmp_path, 11)
+    video, bits = _reference_files(tmp_path, "full", n)
+    (tmp_path / "out").mkdir()
+    env = {"EC504_HOST_THREADS": str(threads), "EC504_BATCH": str(batch), "EC504_CLI_REPEAT": "2"}
+    if devices:
+        env["EC504_DEVICES"] = devices
+    rc, err = _run(builds[san], str(tmp_path), "images/", "out", "out/v.mpeg", "12", "full", env=env)
+    assert rc == 0, err[-3000:]
+    assert (tmp_path / "out" / "v.mpeg").read_bytes() == video
+    assert (tmp_path / "out" / "v.mpeg.2").read_bytes() == video
+    for k in range(1, n + 1):
+        assert (tmp_path / "out" / f"image_{k}.bit").read_bytes() == bits[k - 1], k
+
+
 def test_threaded_error_paths_and_opt_out(builds, tmp_path):
     """Dimension mismatch found after the parallel decode: -1, only the 27-byte prolog written, no .bit files (what the
     reference leaves behind, encoder.h:175-183); EC504_WRITE_BIT=0 skips the side files; an empty folder gives -1."""
