@@ -1618,6 +1618,8 @@ struct m1v_encoder {
     bool tiles;        // the path configure_path set up
     int tile_cols, tile_rows, tiles_per_frame, tile_ring;
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
+    uint16_t *d_tile_order;  // tile-row processing order of the tile kernel (tile_row_order_for), [tile_rows]
+    int tile_order_rows;     // for how many tile rows d_tile_order was built
     size_t meta_bytes, seg_bytes; // sizes of run_meta and seg in effect
     int segs;               // segments per strip: tile rows (tiles), or the most runs a strip can touch (run kernels)
     Tables *d_tab;
@@ -1699,6 +1701,26 @@ size_t m1v_file_prolog(uint8_t out[27]) {
 #ifndef M1V_TILE_RING
 #define M1V_TILE_RING 2
 #endif
+// The order in which a frame's tile rows are processed.  Tile row R (macroblock rows 4R..4R+3) reads its luma from picture
+// rows [64R, 64R+64) and — the chroma quirk, encoder.h:347-348 — its chroma from rows [16R, 16R+16), i.e. from the luma
+// region of tile row R/4.  Top to bottom the second read comes 0.75 R tile rows after the first: at 3840x2160 (737 KB per
+// tile row, 4 MB of L2 per XCD) four chroma reads in five miss L2 and the kernel moves 1.22x its algorithmic bytes.  A
+// depth-first walk of the tree "R is the parent of 4R .. 4R+3" puts every tile row right behind the region its chroma comes
+// from (first children) or a few rows later (later children of a leaf parent): the misses fall to the later children of the
+// few inner nodes.
+static void tile_row_order_for(int tile_rows, std::vector<uint16_t> &order) {
+    order.clear();
+    std::vector<int> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int r = stack.back();
+        stack.pop_back();
+        order.push_back((uint16_t)r);
+        for (int c = 4 * r + 3; c >= 4 * r; c--) // children pushed in reverse: taken in ascending order
+            if (c > 0 && c < tile_rows) stack.push_back(c);
+    }
+}
+
 static int g_fail_alloc_in = 0; // test hook (m1v_debug_fail_alloc): the n-th allocation of configure_path from now fails
 static hipError_t plan_malloc(void **p, size_t bytes) {
     if (g_fail_alloc_in > 0 && --g_fail_alloc_in == 0) return hipErrorOutOfMemory;
@@ -1719,9 +1741,11 @@ static int configure_path(m1v_encoder *e) {
     } plan = {};
     // Tiles by default wherever the run kernel cannot use its aligned 24-byte row loads (widths that are not a multiple of 8,
     // buffers off a 4-byte boundary): there the tile kernel is 1.3-4x faster (profiles/r03_paths_by_geometry.txt).  On
-    // aligned pictures the two kernels run within 1-2 % of each other and the run kernel's gather is cheaper.
+    // aligned pictures the two kernels run within 1-2 % of each other and the run kernel's gather is cheaper — unless the
+    // picture's top quarter (the source of every chroma block) outgrows an XCD's L2: the tile kernel then keeps the chroma
+    // re-reads in L2 by the order of its tile rows (tile_row_order_for), the run kernel re-fetches them from memory.
     plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0) &&
-                 (e->forced_path == 1 || !e->fast_ok || e->prefer_tiles);
+                 (e->forced_path == 1 || !e->fast_ok || e->prefer_tiles || g.frame_bytes / 4 > (3ull << 20));
     size_t need, meta = 0, segb = 0;
     int segs = 0; // segments per strip
     if (plan.tiles) {
@@ -1830,6 +1854,17 @@ static int configure_path(m1v_encoder *e) {
             if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
         }
     }
+    if (plan.tiles && e->tile_order_rows != plan.tile_rows) {
+        std::vector<uint16_t> order;
+        tile_row_order_for(plan.tile_rows, order);
+        (void)hipFree(e->d_tile_order);
+        e->d_tile_order = nullptr;
+        e->tile_order_rows = 0;
+        if (hipMalloc(&e->d_tile_order, order.size() * sizeof(uint16_t)) != hipSuccess ||
+            hipMemcpy(e->d_tile_order, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(M1V_E_HIP, "allocation failed%s");
+        e->tile_order_rows = plan.tile_rows;
+    }
     e->tiles = plan.tiles;
     e->tile_cols = plan.tile_cols; e->tile_rows = plan.tile_rows; e->tiles_per_frame = plan.tiles_per_frame;
     e->tile_ring = plan.tile_ring;
@@ -1897,6 +1932,8 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->luma_region = e->chroma_region = 0;
     e->meta_bytes = e->seg_bytes = 0;
     e->segs = 0;
+    e->d_tile_order = nullptr;
+    e->tile_order_rows = 0;
     e->runs_per_frame = 0;
     e->run_cap = e->slot_bytes = e->arena_slots = 0;
     e->arena_off = 0;
@@ -1974,6 +2011,7 @@ void m1v_destroy(m1v_encoder *e) {
     for (hipEvent_t ev : e->hp.uploaded)
         if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(e->d_stamps);
+    (void)hipFree(e->d_tile_order);
     delete e;
 }
 
@@ -2196,6 +2234,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.tile_cols = e->tile_cols;
         a.tile_rows = e->tile_rows;
         a.tiles_per_frame = e->tiles_per_frame;
+        a.tile_row_order = e->d_tile_order;
         a.lds_words = e->image_words;
         a.run_cap = e->run_cap;
         a.luma_region = e->luma_region;

@@ -46,6 +46,7 @@ struct TileArgs {
     uint32_t *status;
     int n_frames;
     int tile_cols, tile_rows, tiles_per_frame;
+    const uint16_t *tile_row_order; // [tile_rows]: which tile row the k-th group of tile_cols workgroups of a frame takes
     int lds_words;          // capacity of the LDS image of the tile's bits
     uint32_t run_cap;       // bytes of one arena slot: the worst case of a tile
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
@@ -249,7 +250,11 @@ void k_encode_tiles(TileArgs a) {
 
     int frame, tile;
     frame_strip_of(blockIdx.x, a.n_frames, a.tiles_per_frame, frame, tile);
-    const int tr = tile / a.tile_cols, tc = tile - tr * a.tile_cols;
+    // Tile rows are taken in an order that keeps the chroma quirk's re-reads in L2 (tile_row_order_for): the tile's position
+    // in that order only decides WHEN it runs; everything it writes is indexed by the tile row itself.
+    const int tk = tile / a.tile_cols, tc = tile - tk * a.tile_cols;
+    const int tr = a.tile_row_order[tk];
+    tile = tr * a.tile_cols + tc;
     const int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
     const unsigned long long tile_index = (unsigned long long)frame * a.tiles_per_frame + tile;
