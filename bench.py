@@ -12,10 +12,12 @@ grouped send/recv to rank 0 over RCCL; --gather host: every rank copies its bits
 of one pinned host buffer), one host wait per step on eight pinned bytes per rank, nothing allocated
 inside the loop.  Rank 0 prints ONE JSON line.
 
-The line's `roofline` prices the dominant kernel (k_encode_dense) against HBM with its time from HIP events
-recorded on the launch stream inside the library (per launch: min / median / max), carries the HBM bytes of
-the committed PMC passes (`traffic`), and says what the time is made of (`binding`, `valu`): see DESIGN.md,
-"Where the time goes".  `cpu_baseline` is the oracle timed on this box's host cores (bounded samples).
+The line's `roofline` prices the dominant kernel (k_encode_dense on aligned 1080p, k_encode_tiles on pictures whose top
+quarter outgrows L2 and on unaligned input; --path forces one) against HBM with its time from HIP events recorded on
+the launch stream inside the library (per launch: min / median / max), carries the HBM bytes of the committed PMC
+passes (`traffic`, `pmc_fresh`), and says what the time is made of (`binding`, `valu`): see DESIGN.md, "Where the
+time goes".  `host_delivery`: the same steps with every batch's records delivered to pinned host memory under the
+next encode.  `cpu_baseline` is the oracle timed on this box's host cores (bounded samples).
 """
 import argparse
 import json
@@ -88,14 +90,25 @@ def cpu_baseline(W, H, qf, seed, gpu_head=None, budget_s=10.0):
     return out
 
 
-def _committed_pmc(W, H, n):
-    """The committed rocprofv3 PMC record of this workload on the shipped kernel (profiles/r02_pmc.json, written by
-    tools/pmc_record.py from the CSVs of tools/pmc.sh), or None.  PMC cannot be collected from inside this process."""
+def _pmc_sources_sha256(sources):
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()
+
+
+def _committed_pmc(W, H, n, kernel="k_encode_dense"):
+    """The committed rocprofv3 PMC record of this workload and kernel (profiles/r03_pmc.json, written by
+    tools/pmc_record_r03.py from the summaries of tools/pmc_r03.sh), or None.  PMC cannot be collected from inside this
+    process; the record names the kernel sources it was measured on, and `fresh` says whether they are still the tree's."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            for rec in json.load(f)["workloads"]:
-                if [rec["width"], rec["height"], rec["frames"]] == [W, H, n]:
-                    return rec
+        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
+            doc = json.load(f)
+        fresh = _pmc_sources_sha256(doc["sources"]) == doc["source_sha256"]
+        for rec in doc["workloads"]:
+            if [rec["width"], rec["height"], rec["frames"], rec["kernel"]] == [W, H, n, kernel]:
+                return dict(rec, fresh=fresh)
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -364,7 +377,8 @@ def main():
         out_per_frame = total_bytes / n
         alg_bytes_frame = 3 * W * H + out_per_frame            # RGB read once + emitted bytes
         k_ms = kernel_ms / max(launches, 1)
-        pmc = _committed_pmc(W, H, n)
+        kernel_name = "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense"
+        pmc = _committed_pmc(W, H, n, kernel_name)
         achieved = alg_bytes_frame * n / (k_ms * 1e-3) / 1e9 if launches else 0.0
         line = {
             "metric": "1080p I-frames/s" if (W, H) == (1920, 1080) else f"{W}x{H} I-frames/s",
@@ -383,12 +397,13 @@ def main():
                             ", every rank copies its bitstream into its slice of one pinned host buffer") if distributed else "")},
             # "hbm" is the roofline BASELINE.json prices the path against.  What the time is made of today: vector-ALU issue
             # ("valu": ~0.8 of the kernel time) plus memory latency that 5 waves per SIMD do not hide
-            "roofline": {"bound": "hbm", "kernel": "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(pmc),
+                         "pmc_fresh": bool(pmc and pmc.get("fresh")), "l1_to_l2_read_requests_per_pixel_line": round(pmc["l1_to_l2_read_requests"] / pmc["pixel_lines_128B"], 3) if pmc else None,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
                          "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,
                          "kernel_ms_max": round(max(kernel_times), 4) if kernel_times else None, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "valu-issue + exposed load latency (5 waves/SIMD; L1 stalled on pending fills 61 % of cycles)",
+                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "vector-ALU issue (~0.8 of the kernel time; two-slot instructions included the VALU is ~0.9 busy): neither kernel waits for HBM (frames resident in the Infinity Cache run no faster)",
                          "valu": valu_roofline(pmc, k_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1288,10 +1288,10 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
 }
 
 // One workgroup per frame: the run segments of every strip, in the form the gather takes them (k_gather_segments in
-// m1v_tiles.h): seg[frame][strip][q] = (bits, where) and seg_pre = the bit offset of segment q inside its strip, padded with
-// empty segments up to `segs` per strip; then strip byte counts and the exclusive scan of the strips.
+// m1v_tiles.h): seg[frame][strip][q] = (bits, where), padded with empty segments up to `segs` per strip; then strip byte
+// counts and the exclusive scan of the strips.
 __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int segs, const uint32_t *run_meta, uint2 *seg,
-                                                            uint32_t *seg_pre, uint32_t *strip_bytes, uint32_t *strip_off,
+                                                            uint32_t *strip_bytes, uint32_t *strip_off,
                                                             unsigned long long *frame_size) {
     __shared__ uint32_t ws[32];
     const int f = blockIdx.x;
@@ -1308,7 +1308,6 @@ __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int seg
                 uint32_t boff = 0, L = 0;
                 if (w_lo + q <= w_hi) L = dense_segment(d, mf, w_lo + q, s, boff);
                 seg[i * segs + q] = make_uint2(L, boff);
-                seg_pre[i * segs + q] = bits;
                 bits += L;
             }
             nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
@@ -1629,7 +1628,7 @@ struct m1v_encoder {
         uint8_t *scratch;
         uint32_t *run_meta;     // run kernels: [frame][run][4]
         uint2 *seg;             // [frame][strip][segment] (bits, where): what a strip is concatenated from
-        uint32_t *seg_pre;      // bit offset of each segment inside its strip
+        uint32_t *strip_bits;   // tile kernel: bits of every strip, added up by the tiles (k_tile_layout reads and clears it)
         uint32_t *strip_bytes, *strip_off;
         unsigned long long *frame_size, *frame_off;
         uint32_t *status;
@@ -1799,7 +1798,7 @@ static int configure_path(m1v_encoder *e) {
     segb = (size_t)e->max_frames * g.n_strips * segs * sizeof(uint2);
     struct Fresh {
         uint8_t *scratch;
-        void *meta, *seg, *pre;
+        void *meta, *seg;
         bool new_scratch, new_meta, new_seg;
     } fresh[2] = {};
     bool ok = true;
@@ -1812,14 +1811,12 @@ static int configure_path(m1v_encoder *e) {
         if (f.new_scratch) ok = plan_malloc((void **)&f.scratch, need) == hipSuccess;
         if (ok && f.new_meta) ok = plan_malloc(&f.meta, meta) == hipSuccess;
         if (ok && f.new_seg) ok = plan_malloc(&f.seg, segb) == hipSuccess;
-        if (ok && f.new_seg) ok = plan_malloc(&f.pre, segb / 2) == hipSuccess;
     }
     if (!ok) {
         for (Fresh &f : fresh) {
             (void)hipFree(f.scratch);
             (void)hipFree(f.meta);
             (void)hipFree(f.seg);
-            (void)hipFree(f.pre);
         }
         (void)hipGetLastError();
         return fail(M1V_E_HIP, "scratch allocation failed (the encoder keeps its previous configuration)%s");
@@ -1837,14 +1834,14 @@ static int configure_path(m1v_encoder *e) {
         }
         if (f.new_seg) {
             (void)hipFree(bt.seg);
-            (void)hipFree(bt.seg_pre);
             bt.seg = (uint2 *)f.seg;
-            bt.seg_pre = (uint32_t *)f.pre;
         }
         size_t nslots = (size_t)e->max_frames * g.n_strips;
         if (!bt.strip_bytes) {
             hipError_t err = hipMalloc(&bt.strip_bytes, nslots * sizeof(uint32_t));
             if (err == hipSuccess) err = hipMalloc(&bt.strip_off, nslots * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMalloc(&bt.strip_bits, nslots * sizeof(uint32_t));
+            if (err == hipSuccess) err = hipMemset(bt.strip_bits, 0, nslots * sizeof(uint32_t));
             if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
             if (err == hipSuccess) err = hipMalloc(&bt.status, 4 * sizeof(uint32_t)); // [0] encode status, [1] sink, [2] arena counter
@@ -1992,7 +1989,7 @@ void m1v_destroy(m1v_encoder *e) {
         (void)hipFree(bt.scratch);
         (void)hipFree(bt.run_meta);
         (void)hipFree(bt.seg);
-        (void)hipFree(bt.seg_pre);
+        (void)hipFree(bt.strip_bits);
         (void)hipFree(bt.strip_bytes);
         (void)hipFree(bt.strip_off);
         (void)hipFree(bt.frame_size);
@@ -2216,7 +2213,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     l.n_frames = n_frames;
     l.n_strips = g.n_strips;
 
-    if (!bt.scratch || ((e->tiles || e->dense) && (!bt.seg || !bt.seg_pre)) || (!e->tiles && e->dense && !bt.run_meta))
+    if (!bt.scratch || ((e->tiles || e->dense) && !bt.seg) || (!e->tiles && e->dense && !bt.run_meta))
         return fail(M1V_E_HIP, "the encoder has no scratch (an earlier allocation failed)%s");
     if (e->tiles) {
         TileArgs a;
@@ -2225,6 +2222,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.tab = e->d_tab;
         a.scratch = bt.scratch;
         a.seg = bt.seg;
+        a.strip_bits = bt.strip_bits;
         a.arena_next = bt.status + 2;
         a.slot_bytes = e->slot_bytes;
         a.arena_slots = e->arena_slots;
@@ -2258,14 +2256,12 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.n_frames = n_frames;
         d.n_strips = g.n_strips;
         d.segs = e->tile_rows;
-        hipLaunchKernelGGL(k_tile_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.seg, bt.seg_pre, bt.strip_bytes, bt.strip_off,
-                           bt.frame_size);
+        hipLaunchKernelGGL(k_tile_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.strip_bits, bt.strip_bytes, bt.strip_off, bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
         SegGatherArgs ga;
         ga.d = d;
         ga.scratch = bt.scratch;
         ga.seg = bt.seg;
-        ga.seg_pre = bt.seg_pre;
         ga.strip_bytes = bt.strip_bytes;
         ga.strip_off = bt.strip_off;
         ga.frame_size = bt.frame_size;
@@ -2276,7 +2272,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.status = d_status ? d_status : bt.status + 1;
         ga.first_index = first_frame_index;
         hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
-                           (size_t)kGatherStrips * (3 * e->tile_rows + 1) * sizeof(uint32_t), gs, ga);
+                           (size_t)kGatherStrips * (3 * e->tile_rows + 1 + 4 * kWave) * sizeof(uint32_t), gs, ga);
         HIP_TRY(hipGetLastError());
     } else if (e->dense) {
         DenseArgs a;
@@ -2339,8 +2335,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.bps = g.n_mbrows * 6;
         d.T = e->dense_T;
         d.runs_per_frame = e->runs_per_frame;
-        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, e->segs, bt.run_meta, bt.seg, bt.seg_pre,
-                           bt.strip_bytes, bt.strip_off, bt.frame_size);
+        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, e->segs, bt.run_meta, bt.seg, bt.strip_bytes,
+                           bt.strip_off, bt.frame_size);
         hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
         SegGatherArgs ga;
         ga.d.n_frames = n_frames;
@@ -2348,7 +2344,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.d.segs = e->segs;
         ga.scratch = bt.scratch;
         ga.seg = bt.seg;
-        ga.seg_pre = bt.seg_pre;
         ga.strip_bytes = bt.strip_bytes;
         ga.strip_off = bt.strip_off;
         ga.frame_size = bt.frame_size;
@@ -2359,7 +2354,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.status = d_status ? d_status : bt.status + 1;
         ga.first_index = first_frame_index;
         hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
-                           (size_t)kGatherStrips * (3 * e->segs + 1) * sizeof(uint32_t), gs, ga);
+                           (size_t)kGatherStrips * (3 * e->segs + 1 + 4 * kWave) * sizeof(uint32_t), gs, ga);
         HIP_TRY(hipGetLastError());
     } else {
         EncodeArgs a;

@@ -40,6 +40,7 @@ struct TileArgs {
     const Tables *tab;
     uint8_t *scratch;       // [frame][tile][slot_bytes] compact slots, then the overflow arena (as the run kernels)
     uint2 *seg;             // [frame][strip][tile row]: bits of the segment, where it starts (4-byte words from `scratch`)
+    uint32_t *strip_bits;   // [frame][strip]: every tile adds its segments' bits (zero before the batch: k_tile_layout clears it)
     uint32_t *arena_next;
     uint32_t slot_bytes, arena_slots;
     unsigned long long arena_off;
@@ -387,6 +388,7 @@ void k_encode_tiles(TileArgs a) {
         if (wave == 0 && lane < strips_here) {
             slice_headers(big, true);
             *seg_out = make_uint2(seg_bits, (uint32_t)(where >> 2) + (seg_incl - seg_words));
+            atomicAdd(&a.strip_bits[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], seg_bits);
         }
         if (valid) put_block<true>(big, off, bb, walk);
         if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
@@ -397,6 +399,7 @@ void k_encode_tiles(TileArgs a) {
     if (wave == 0 && lane < strips_here) {
         slice_headers(image, false);
         *seg_out = make_uint2(seg_bits, (uint32_t)((tile_index * a.slot_bytes) >> 2) + (seg_incl - seg_words));
+        atomicAdd(&a.strip_bits[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], seg_bits);
     }
     if (valid) put_block<false>(image, off, bb, walk);
     TSTAMP(7);
@@ -486,9 +489,10 @@ struct SegGeom {
     int n_frames, n_strips, segs; // segs = segments per strip (tile rows here; k_dense_frame_layout pads to its own count)
 };
 
-// One workgroup per frame: bit prefix of every strip's segments, strip byte counts, exclusive scan of the strips.
-__global__ __launch_bounds__(256) void k_tile_layout(SegGeom d, const uint2 *seg, uint32_t *seg_pre, uint32_t *strip_bytes,
-                                                     uint32_t *strip_off, unsigned long long *frame_size) {
+// One workgroup per frame: strip byte counts from the bit totals the tiles added up (cleared here for the next batch),
+// exclusive scan of the strips.
+__global__ __launch_bounds__(256) void k_tile_layout(SegGeom d, uint32_t *strip_bits, uint32_t *strip_bytes, uint32_t *strip_off,
+                                                     unsigned long long *frame_size) {
     __shared__ uint32_t ws[32];
     const int f = blockIdx.x;
     uint32_t run_total = 0;
@@ -497,12 +501,8 @@ __global__ __launch_bounds__(256) void k_tile_layout(SegGeom d, const uint2 *seg
         uint32_t nbytes = 0;
         if (s < d.n_strips) {
             const size_t i = (size_t)f * d.n_strips + s;
-            uint32_t bits = 0;
-            for (int t = 0; t < d.segs; t++) {
-                seg_pre[i * d.segs + t] = bits;
-                bits += seg[i * d.segs + t].x;
-            }
-            nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+            nbytes = (strip_bits[i] + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
+            strip_bits[i] = 0;
             strip_bytes[i] = nbytes;
         }
         uint32_t tot;
@@ -517,7 +517,7 @@ struct SegGatherArgs {
     SegGeom d;
     const uint8_t *scratch;
     const uint2 *seg;
-    const uint32_t *seg_pre, *strip_bytes, *strip_off;
+    const uint32_t *strip_bytes, *strip_off;
     const unsigned long long *frame_size, *frame_off;
     const Tables *tab;
     uint8_t *out;
@@ -529,7 +529,7 @@ struct SegGatherArgs {
 // One wave per strip, kGatherStrips strips per workgroup ; a wave keeps its strip's segment table in
 // its own part of LDS (written and read by the same wave: no barrier).
 __global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGatherArgs a) {
-    extern __shared__ uint32_t gl_all[]; // per wave: [tile_rows + 1] bit prefix, [tile_rows] bits, [tile_rows] source word offset
+    extern __shared__ uint32_t gl_all[]; // per wave: [segs + 1] bit prefix, [segs] bits, [segs] source word offset, [256] segment starts per output word
     const SegGeom &d = a.d;
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = (int)blockIdx.x * kGatherStrips + wave, f = blockIdx.y, T = d.segs;
@@ -540,13 +540,20 @@ __global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGa
         return;
     }
     const size_t idx = (size_t)f * d.n_strips + s;
-    uint32_t *gl = gl_all + wave * (3 * T + 1);
-    uint32_t *pre = gl, *bits = gl + T + 1, *src = gl + 2 * T + 1;
-    for (int t = lane; t < T; t += kWave) {
-        const uint2 sg = a.seg[idx * T + t];
-        pre[t] = a.seg_pre[idx * T + t];
-        bits[t] = sg.x;
-        src[t] = sg.y;
+    uint32_t *gl = gl_all + wave * (3 * T + 1 + 4 * kWave);
+    uint32_t *pre = gl, *bits = gl + T + 1, *src = gl + 2 * T + 1, *starts = gl + 3 * T + 1;
+    // the strip's segment table: (bits, where) from memory, the bit offset of each segment by a wave scan over the tile rows
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < T; t0 += kWave) {
+        const int t = t0 + lane;
+        const uint2 sg = t < T ? a.seg[idx * T + t] : make_uint2(0u, 0u);
+        const uint32_t incl = wave_scan_inclusive(sg.x);
+        if (t < T) {
+            pre[t] = carry + incl - sg.x;
+            bits[t] = sg.x;
+            src[t] = sg.y;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
     }
     const uint32_t n = a.strip_bytes[idx];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the table is this wave's own: program order is enough
@@ -554,15 +561,27 @@ __global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGa
     const uint32_t nwords = (n + 3) >> 2;
     // Four output words per lane and trip: their segment searches, then all source loads (unconditional, masked afterwards),
     // then the stores — one memory latency per trip, and a strip (~1 KB) is one trip.
-    for (uint32_t w0 = lane; w0 < nwords; w0 += 4 * kWave) {
+    for (uint32_t base = 0; base < nwords; base += 4 * kWave) { // wave-uniform trips: every lane takes part in the counting
+        const uint32_t w0 = base + lane;
+        // k = the last segment that starts at or before the word's first bit = (segments that start at or before it) - 1.
+        // Counted, not searched (a binary search per word is five dependent LDS reads): every segment marks the first word
+        // that begins at or behind its start, a prefix sum over the trip's 256 words does the rest.
+#pragma unroll
+        for (int u = 0; u < 4; u++) starts[u * kWave + lane] = 0;
+        uint32_t before = 0; // segments that start before this trip's first word
+        for (int t0 = 0; t0 < T; t0 += kWave) {
+            const int t = t0 + lane;
+            const uint32_t wf = t < T ? (pre[t] + 31u) >> 5 : 0xffffffffu; // first word that begins at or behind the segment's start
+            before += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wf <= base));
+            if (wf > base && wf - base < 4u * kWave) atomicAdd(&starts[wf - base], 1u);
+        }
         int k[4];
+        uint32_t run = before;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t lo_bit = 32u * (w0 + u * kWave);
-            int kk = 0; // last segment that starts at or before lo_bit
-            for (int step = 1 << (31 - __builtin_clz((unsigned)T | 1u)); step > 0; step >>= 1)
-                if (kk + step < T && pre[kk + step] <= lo_bit) kk += step;
-            k[u] = kk;
+            const uint32_t incl = wave_scan_inclusive(starts[u * kWave + lane]);
+            k[u] = (int)(run + incl) - 1;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
         }
         unsigned long long win[4][2];
         uint32_t sh[4][2], nb[4][2], at[4][2];
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGa
             }
             // (a third segment inside one word: only when a segment is shorter than 32 bits, i.e. a last tile row of one
             //  macroblock row of all-minimal blocks)
-            for (int kk = k[u] + 2; kk < T && pre[kk] < lo_bit + 32u; kk++)
+            for (int kk = k[u] + 2; w < nwords && kk < T && pre[kk] < lo_bit + 32u; kk++)
                 val |= strip_bits_from(a.scratch + (size_t)src[kk] * 4, pre[kk], bits[kk], lo_bit);
             if (w < nwords) {
                 const uint32_t b0 = 4u * w;

@@ -29,5 +29,5 @@ TCC_REQ_sum TCC_READ_sum TCC_BUSY_sum TCC_TAG_STALL_sum
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_HIT_sum TCC_MISS_sum
 GROUPS
 python3 $ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-rm -rf $OUT/p*/   # the raw CSV trees are large; the summary is what gets committed
+rm -rf $OUT/p*/   # the raw CSV trees are large; the summary (with the mean dispatch durations) is what gets committed
 cat $OUT/summary.txt
