@@ -19,7 +19,7 @@
 //     exact real the fma adds to the third operand before its single rounding — which does not round, because the sum
 //     is again N * 2^-s with |N| < 2^24.
 //   floor(N * 2^-s) is the reference's arithmetic right shift.  The two row outputs (t * 181) >> 17 exceed 24 bits in the
-//   product and go through the integer multiplier.  tools/fdct_f32_proof.cpp instantiates the network with a checked
+//   product: see fdct_row_f for the two forms (integer multiplier, or one multiply rounded toward minus infinity).  tools/fdct_f32_proof.cpp instantiates the network with a checked
 //   number type (every operation computed exactly, failing if a result is not an fp32 value) on worst-case and random
 //   blocks, and compares the float instantiation with the integer network.
 #pragma once
@@ -27,9 +27,6 @@
 
 #ifndef M1V_HD
 #define M1V_HD inline
-#endif
-#ifndef M1V_MUL24
-#define M1V_MUL24(a, b) ((a) * (b))
 #endif
 
 namespace m1vf {
@@ -39,6 +36,25 @@ namespace m1vf {
 M1V_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 M1V_HD float floor_(float a) { return floorf(a); }
 M1V_HD int to_int(float a) { return (int)a; }
+// a * k rounded toward minus infinity.  Device: a plain multiply — the caller's wave runs its fp32 arithmetic in that mode
+// (pixel_stage_rounding() in m1v_kernels.hip, first statement of every kernel that instantiates fdct_row_f<F, true>).
+M1V_HD float mul_down(float a, float k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * k;
+#else
+    const double p = (double)a * (double)k; // exact: 24 x 24 bits
+    float f = (float)p;
+    if ((double)f > p) f = nextafterf(f, -INFINITY);
+    return f;
+#endif
+}
+M1V_HD int mulhi_(int a, int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mulhi(a, b);
+#else
+    return (int)(((long long)a * (long long)b) >> 32);
+#endif
+}
 
 // raw pixels carry this bias through the transform; only the DC sum keeps it (64 * kPxBiasF, removed in fdct_col_f)
 constexpr float kPxBiasF = 256.0f;
@@ -81,7 +97,16 @@ M1V_HD void butterfly8f(const F v0, const F v1, const F v2, const F v3, const F 
 
 // Row pass (image_processing.c:198-250): 8 raw pixels (kPxBiasF + value) -> out[0..7], integers held in floats.
 // out[0] carries 8 * kPxBiasF.
-template <typename F>
+// The two outputs (x * 181) >> 17 need 28 bits in the product:
+//   DOWN = false  through the integer multiplier: the high half of x * (181 << 15) = (x * 181 * 2^15) >> 32 is the product and
+//                 the shift in one v_mul_hi_i32 (a v_mul_i32_i24 inside a stream of float instructions costs 20-45 cycles on
+//                 gfx950, tools/ubench/stream_probe.hip; v_mul_lo_u32 + shift measured 3 % slower than this in the kernel);
+//   DOWN = true   x * 181 / 2^17 = t * (181 / 128) as ONE float multiply rounded TOWARD MINUS INFINITY: the rounded product
+//                 cannot fall below the integer under the exact value (that integer is a float <= the exact value) and is
+//                 never above the exact value, so its floor is the exact value's floor.  Needs the wave in that rounding mode;
+//                 every other operation of both passes is exact and does not care.  Two conversions and the integer multiply
+//                 per output less (profiles/r03_ab_history.txt).
+template <typename F, bool DOWN = false>
 M1V_HD void fdct_row_f(const F p[8], F out[8]) {
     F t[8];
     butterfly8f<10, false, F>(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], t);
@@ -91,11 +116,13 @@ M1V_HD void fdct_row_f(const F p[8], F out[8]) {
     out[6] = floor_(t[3]); // x7 >> 10
     out[7] = floor_(t[4]); // (x2 - x5) >> 10
     out[1] = floor_(t[5]); // (x2 + x5) >> 10
-    // (x * 181) >> 17: the product needs 28 bits, so these two go through the integer multiplier — the 32-bit one
-    // (v_mul_lo_u32): a v_mul_i32_i24 inside a stream of float instructions costs 20-45 cycles on gfx950
-    // (tools/ubench/stream_probe.hip, profiles/r02_stream_probe.txt), v_mul_lo_u32 about 5
-    out[3] = F((float)(M1V_MUL24(to_int(t[6] * F(1024.0f)), 181) >> 17));
-    out[5] = F((float)(M1V_MUL24(to_int(t[7] * F(1024.0f)), 181) >> 17));
+    if (DOWN) {
+        out[3] = floor_(mul_down(t[6], F(181.0f / 128.0f)));
+        out[5] = floor_(mul_down(t[7], F(181.0f / 128.0f)));
+    } else {
+        out[3] = F((float)mulhi_(to_int(t[6] * F(1024.0f)), 181 << 15));
+        out[5] = F((float)mulhi_(to_int(t[7] * F(1024.0f)), 181 << 15));
+    }
 }
 
 // Column pass (image_processing.c:253-305): rows[0..7][i] -> dct_block[0..7][i].  dc_bias8 = (what the column's plain

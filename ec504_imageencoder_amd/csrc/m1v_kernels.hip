@@ -222,6 +222,25 @@ __device__ __forceinline__ float component_raw(uint32_t r, uint32_t g, uint32_t 
 
 #define M1V_CONST_AS __attribute__((address_space(4)))
 
+#ifndef M1V_MIX_COLOUR
+#define M1V_MIX_COLOUR 0
+#endif
+
+// The tile kernels run their fp32 arithmetic rounded TOWARD MINUS INFINITY: fdct_row_f<float, true> takes two floors of
+// products that round (fdct_f32.h) and needs that mode; the colour sums are proven for it as well as for the default
+// (tools/colour_fast_proof.c down: the same pixels are flagged, none is wrong), the reciprocal quantiser likewise
+// (tests/test_host_tables.py), and everything else in the stage is exact.  MODE[1:0] = 2; the fp64 mode bits (the colour
+// fallback re-evaluates the reference's expression) stay at round-to-nearest.  The frame's base pointer passes through the
+// statement, so no load of a pixel — and no arithmetic on one — can be scheduled in front of the switch; so do the two tile
+// coordinates, the results of the kernel's last integer divisions (the compiler expands those through v_rcp_iflag_f32 and a
+// float multiply: they stay in the default mode; tests/test_abi.py checks the code object for both).
+// The run kernel keeps the default mode and the integer form: measured 1 % faster there (profiles/r03_ab_history.txt).
+__device__ __forceinline__ const uint8_t *pixel_stage_rounds_down(const uint8_t *frame_base, int &u0, int &u1) {
+    unsigned long long p = (unsigned long long)(uintptr_t)frame_base;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2" : "+s"(p), "+s"(u0), "+s"(u1));
+    return (const uint8_t *)(uintptr_t)p;
+}
+
 struct __attribute__((aligned(4))) Row24 {
     uint32_t d[6];
 };
@@ -236,10 +255,42 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
     float lowest = 1.0f;
+#if M1V_MIX_COLOUR
+    // Byte -> float and the multiply-add in ONE instruction: a byte alone in a 16-bit half is the f16 denormal b * 2^-24, which
+    // v_fma_mix_f32 widens exactly; with the coefficient scaled by 2^24 (exact) the product is the same real number k * b, so
+    // the single rounding of the fma returns the bits of fmaf((float)b, k, acc).  Two fast instructions per register isolate
+    // its even bytes (& 0x00ff00ff) and three its odd ones (>> 8 first), against one conversion per byte.
+    constexpr int kRegs = (int)(sizeof(RowT) / 4);
+    uint32_t even[kRegs], odd[kRegs];
+#pragma unroll
+    for (int i = 0; i < kRegs; i++) {
+        even[i] = v.d[i] & 0x00ff00ffu;
+        odd[i] = (v.d[i] >> 8) & 0x00ff00ffu;
+    }
+    const float mr = k.kr * 16777216.0f, mg = k.kg * 16777216.0f, mb = k.kb * 16777216.0f;
+    auto mix = [&](int byte, float kk, float acc) -> float {
+        const uint32_t src = (byte & 1) ? odd[byte >> 2] : even[byte >> 2];
+        float r;
+        if (byte & 2)
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(src), "v"(kk), "v"(acc));
+        else
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(src), "v"(kk), "v"(acc));
+        return r;
+    };
+    auto component_mix = [&](int j) -> float {
+        float t = mix(BPP * j + 2, mb, k.k0);
+        t = mix(BPP * j + 1, mg, t);
+        return mix(BPP * j, mr, t);
+    };
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
+#if M1V_MIX_COLOUR
+        const float t0 = component_mix(j), t1 = component_mix(j + 1);
+#else
         const float t0 = component_t(chan(j, 0), chan(j, 1), chan(j, 2), k);
         const float t1 = component_t(chan(j + 1, 0), chan(j + 1, 1), chan(j + 1, 2), k);
+#endif
         out[j] = clear_fraction(t0);
         out[j + 1] = clear_fraction(t1);
         lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
@@ -330,7 +381,7 @@ __device__ __forceinline__ void block_coefficients(const Geometry &g, const uint
     for (int i = 0; i < 8; i++) {
         float px[8];
         load_row<FAST>(frame + (size_t)((s.first + (uint32_t)i * s.stride) * (uint32_t)g.C), g.C, k, px);
-        m1vf::fdct_row_f<float>(px, &rows[i * 8]);
+        m1vf::fdct_row_f<float, false>(px, &rows[i * 8]);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -706,7 +757,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
             load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
         float ro[8];
-        m1vf::fdct_row_f<float>(px, ro);
+        m1vf::fdct_row_f<float, false>(px, ro);
         rows.put(i, ro);
     }
     int dc = 0;
@@ -1617,7 +1668,7 @@ struct m1v_encoder {
     bool tiles;        // the path configure_path set up
     int tile_cols, tile_rows, tiles_per_frame, tile_ring;
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
-    uint16_t *d_tile_order;  // tile-row processing order of the tile kernel (tile_row_order_for), [tile_rows]
+    uint32_t *d_tile_order;  // tile-row processing order of the tile kernel (tile_row_order_for), [tile_rows]
     int tile_order_rows;     // for how many tile rows d_tile_order was built
     size_t meta_bytes, seg_bytes; // sizes of run_meta and seg in effect
     int segs;               // segments per strip: tile rows (tiles), or the most runs a strip can touch (run kernels)
@@ -1707,14 +1758,14 @@ size_t m1v_file_prolog(uint8_t out[27]) {
 // depth-first walk of the tree "R is the parent of 4R .. 4R+3" puts every tile row right behind the region its chroma comes
 // from (first children) or a few rows later (later children of a leaf parent): the misses fall to the later children of the
 // few inner nodes.
-static void tile_row_order_for(int tile_rows, std::vector<uint16_t> &order) {
+static void tile_row_order_for(int tile_rows, std::vector<uint32_t> &order) {
     order.clear();
     std::vector<int> stack;
     stack.push_back(0);
     while (!stack.empty()) {
         const int r = stack.back();
         stack.pop_back();
-        order.push_back((uint16_t)r);
+        order.push_back((uint32_t)r);
         for (int c = 4 * r + 3; c >= 4 * r; c--) // children pushed in reverse: taken in ascending order
             if (c > 0 && c < tile_rows) stack.push_back(c);
     }
@@ -1852,13 +1903,13 @@ static int configure_path(m1v_encoder *e) {
         }
     }
     if (plan.tiles && e->tile_order_rows != plan.tile_rows) {
-        std::vector<uint16_t> order;
+        std::vector<uint32_t> order;
         tile_row_order_for(plan.tile_rows, order);
         (void)hipFree(e->d_tile_order);
         e->d_tile_order = nullptr;
         e->tile_order_rows = 0;
-        if (hipMalloc(&e->d_tile_order, order.size() * sizeof(uint16_t)) != hipSuccess ||
-            hipMemcpy(e->d_tile_order, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+        if (hipMalloc(&e->d_tile_order, order.size() * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpy(e->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
             return fail(M1V_E_HIP, "allocation failed%s");
         e->tile_order_rows = plan.tile_rows;
     }
@@ -2053,7 +2104,13 @@ int m1v_set_pipelined(m1v_encoder *e, int enable) {
     const bool before = e->pipelined;
     e->pipelined = enable != 0;
     e->calls = 0;
-    if (e->pipelined && !e->side) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    if (e->pipelined && !e->side) {
+        // highest priority: the few memory-bound workgroups of layout + gather should take the first slots the (much longer,
+        // arithmetic-bound) encode kernel of the next batch frees, not queue behind its whole grid
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, greatest));
+    }
     const int rc = configure_path(e);
     if (rc != M1V_OK) e->pipelined = before; // the second set of buffers could not be allocated: stay as we were
     return rc;

@@ -47,7 +47,7 @@ struct TileArgs {
     uint32_t *status;
     int n_frames;
     int tile_cols, tile_rows, tiles_per_frame;
-    const uint16_t *tile_row_order; // [tile_rows]: which tile row the k-th group of tile_cols workgroups of a frame takes
+    const uint32_t *tile_row_order; // [tile_rows] (32-bit: a scalar load): which tile row the k-th group of tile_cols workgroups of a frame takes
     int lds_words;          // capacity of the LDS image of the tile's bits
     uint32_t run_cap;       // bytes of one arena slot: the worst case of a tile
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
@@ -227,7 +227,7 @@ __device__ __forceinline__ void tile_pixel_rows(const Geometry &g, const uint8_t
         float px[8];
         convert_row<3, M1V_TILE_LEAN>(v, kf, px);
         float ro[8];
-        m1vf::fdct_row_f<float>(px, ro);
+        m1vf::fdct_row_f<float, true>(px, ro); // the wave rounds down: pixel_stage_rounds_down()
         rows.put(i, ro);
     }
 }
@@ -254,10 +254,10 @@ void k_encode_tiles(TileArgs a) {
     // Tile rows are taken in an order that keeps the chroma quirk's re-reads in L2 (tile_row_order_for): the tile's position
     // in that order only decides WHEN it runs; everything it writes is indexed by the tile row itself.
     const int tk = tile / a.tile_cols, tc = tile - tk * a.tile_cols;
-    const int tr = a.tile_row_order[tk];
+    const int tr = (int)a.tile_row_order[tk];
     tile = tr * a.tile_cols + tc;
-    const int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
-    const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+    int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
+    const uint8_t *fbase = pixel_stage_rounds_down(a.rgb + (unsigned long long)frame * g.frame_bytes, s0, m0);
     const unsigned long long tile_index = (unsigned long long)frame * a.tiles_per_frame + tile;
 
     // ---- which block a lane owns: strip j and macroblock row m inside the tile, block inside the macroblock (Y0 Y1 Y2 Y3 Cb Cr) ----
@@ -438,8 +438,8 @@ void k_coefficient_tiles(CoefTileArgs a) {
     int frame, tile;
     frame_strip_of(blockIdx.x, a.n_frames, a.tiles_per_frame, frame, tile);
     const int tr = tile / a.tile_cols, tc = tile - tr * a.tile_cols;
-    const int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
-    const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+    int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
+    const uint8_t *fbase = pixel_stage_rounds_down(a.rgb + (unsigned long long)frame * g.frame_bytes, s0, m0);
     const int strips_here = min(kTileStrips, g.n_strips - s0), mrows_here = min(kTileMbRows, g.n_mbrows - m0);
     const int comp = wave == 2 ? 1 + (lane >> 5) : 0;
 

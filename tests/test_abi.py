@@ -243,3 +243,31 @@ def test_tile_kernel_shape_of_round_3(built):
     assert len(recs) == 2, recs
     for nm, scratch, vgprs in recs:
         assert int(scratch) == 0 and int(vgprs) <= 72, (nm, scratch, vgprs)
+
+
+def test_rounding_mode_of_the_pixel_stage(built):
+    """The tile kernels take (x * 181) >> 17 as floor(t * 181/128) with the multiply rounded toward minus infinity
+    (csrc/fdct_f32.h, fdct_row_f<float, true>), which is only right while the wave IS in that mode.  In the code object:
+    * a kernel multiplies by 181/128 (literal 0x3fb50000) exactly when it switches MODE's fp32 rounding bits, once, to 2;
+    * the switch comes before the first of those multiplies;
+    * nothing of the compiler's integer-division expansion (v_rcp_iflag_f32, u32 <-> f32 conversions), whose error analysis
+      assumes round-to-nearest, comes after the switch."""
+    asm, _ = _gfx950_disassembly()
+    kernels = re.findall(r"<(_ZN\S*)>:\n(.*?)\n\n", asm, re.S)
+    assert kernels
+    switching = []
+    for name, body in kernels:
+        lines = [l.split("//")[0].strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(("/", ";"))]
+        switches = [i for i, l in enumerate(lines) if l.startswith("s_setreg")]
+        muls = [i for i, l in enumerate(lines) if l.startswith("v_mul_f32") and "0x3fb50000" in l]
+        assert bool(switches) == bool(muls), name
+        if not switches:
+            continue
+        switching.append(name)
+        assert len(switches) == 1 and "HW_REG_MODE, 0, 2" in lines[switches[0]].replace("hwreg(", "").replace(")", ""), (name, [lines[i] for i in switches])
+        assert lines[switches[0]].rstrip().endswith(", 2"), lines[switches[0]]
+        assert len(muls) == 16 and switches[0] < muls[0], name
+        late = [l for l in lines[switches[0]:] if l.startswith(("v_rcp", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_div_"))]
+        assert not late, (name, late)
+    assert sorted(n[n.index("k_"):][:18] for n in switching) == ["k_coefficient_tile", "k_encode_tilesILb0", "k_encode_tilesILb1"], switching
+

@@ -14,6 +14,13 @@ def test_reciprocal_quantiser_is_exact():
         assert np.array_equal(got, n // d), d
         # negative side: fp32 multiply and C truncation are both sign-symmetric
         assert np.array_equal((-nf * rq).astype(np.int32), -(n // d)), d
+        # the tile kernels multiply in round-toward-minus-infinity mode (m1v_kernels.hip, pixel_stage_rounds_down): the exact
+        # product (24 x 24 bits: exact in float64) rounded DOWN to fp32, then truncated
+        for sign in (1.0, -1.0):
+            exact = (sign * nf).astype(np.float64) * np.float64(rq)
+            down = exact.astype(np.float32)
+            down = np.where(down.astype(np.float64) > exact, np.nextafter(down, np.float32(-np.inf)), down)
+            assert np.array_equal(down.astype(np.int32), (sign * (n // d)).astype(np.int32)), (d, sign)
 
 
 def test_fdct_output_range(orc):
@@ -53,21 +60,27 @@ def test_narrow_staging_threshold(orc):
 def test_colour_fast_path_proof_over_all_rgb_triples(tmp_path):
     """The kernel's fp32 colour fast path (value and uncertainty flag read from the float's bit pattern, +256 so the
     exponent is fixed) restated on the host and checked for all 2^24 triples x 3 components against the reference's
-    fp64 expression: every pixel it does not flag must already be right (tools/colour_fast_proof.c, 0.5 s)."""
+    fp64 expression: every pixel it does not flag must already be right (tools/colour_fast_proof.c, 0.5 s) — in round-to-nearest
+    (run kernel, plane conversion) and in round-toward-minus-infinity (tile kernels)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "proof")
-    subprocess.run(["gcc", "-O2", "-ffp-contract=off", os.path.join(root, "tools", "colour_fast_proof.c"), "-o", exe, "-lm"], check=True)
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-frounding-math", os.path.join(root, "tools", "colour_fast_proof.c"), "-o", exe, "-lm"],
+                   check=True)
     p = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "wrong: 0" in p.stdout, p.stdout
+    # the tile kernels evaluate the three fmas rounded toward minus infinity: same proof in that mode
+    q = subprocess.run([exe, "down"], stdout=subprocess.PIPE, text=True)
+    assert q.returncode == 0 and "wrong: 0" in q.stdout, q.stdout
 
 
 def test_fp32_fdct_is_exact(tmp_path):
     """The kernel's FDCT runs in fp32 (ec504_imageencoder_amd/csrc/fdct_f32.h).  tools/fdct_f32_proof.cpp instantiates the
     same header (a) with a checked number type that computes every add / multiply / fma / floor exactly and fails if any
     result is not an fp32 value, (b) with float, compared with an integer restatement of image_processing.c:192-307 — on
-    constant blocks, the sign patterns that extremise every linear form of both passes, and 100k random blocks."""
+    constant blocks, the sign patterns that extremise every linear form of both passes, and 100k random blocks; both forms of the two
+    (x * 181) >> 17 outputs of the row pass (integer multiplier; one multiply rounded toward minus infinity)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

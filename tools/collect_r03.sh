@@ -15,6 +15,18 @@ stats() { # tag, frames kept, bench args...
   python3 $ROOT/tools/rocpd_stats.py $(ls $OUT/prof_$tag/*results.db $OUT/prof_$tag/*/*results.db 2>/dev/null | head -1) --last $keep > $OUT/r03_${tag}_kernel_stats_timed.csv
   rm -rf $OUT/prof_$tag
 }
+echo "== pmc (first: the bench lines below read profiles/r03_pmc.json and check its source hash)"
+cd $ROOT
+for p in runs tiles; do
+  bash tools/pmc_r03.sh base $p 1920 1080 300 > $OUT/pmc_1080p_$p.txt 2>&1
+  bash tools/pmc_r03.sh base $p 3840 2160 300 > $OUT/pmc_4k_$p.txt 2>&1
+done
+python3 tools/pmc_record_r03.py gpurun_out/pmc3_base_runs_1920x1080 gpurun_out/pmc3_base_tiles_1920x1080 gpurun_out/pmc3_base_runs_3840x2160 gpurun_out/pmc3_base_tiles_3840x2160 > $OUT/pmc_record.log 2>&1
+cp profiles/r03_pmc.json $OUT/r03_pmc.json
+{ echo "# PMC passes of both encode kernels on the shipped tree (tools/pmc_r03.sh: one rocprofv3 --pmc run per counter group, --kernel-trace only"
+  echo "# beside it), per-dispatch means; 300 frames per launch.  L1->L2 read requests = TCP_TCC_READ_REQ_sum; pixel lines = W*H*3*300/128."
+  for d in runs_1920x1080 tiles_1920x1080 runs_3840x2160 tiles_3840x2160; do echo; echo "===== $d"; cat gpurun_out/pmc3_base_$d/summary.txt; done; } > $OUT/r03_memory_path_pmc.txt
+cd /tmp
 echo "== stats"
 stats 1080p 200
 stats 1080p_tiles 200 --path tiles
@@ -26,12 +38,5 @@ python3 bench.py > $OUT/r03_1080p_bench.json 2> /dev/null
 python3 bench.py --path tiles --no-cpu-baseline > $OUT/r03_1080p_tiles_bench.json 2> /dev/null
 python3 bench.py --no-cpu-baseline --width 3840 --height 2160 --steps 60 --warmup 20 > $OUT/r03_4k_bench.json 2> /dev/null
 python3 bench.py --no-cpu-baseline --width 3840 --height 2160 --steps 60 --warmup 20 --path runs > $OUT/r03_4k_runs_bench.json 2> /dev/null
-echo "== pmc"
-for p in runs tiles; do
-  bash tools/pmc_r03.sh base $p 1920 1080 300 > $OUT/pmc_1080p_$p.txt 2>&1
-  bash tools/pmc_r03.sh base $p 3840 2160 300 > $OUT/pmc_4k_$p.txt 2>&1
-done
-python3 tools/pmc_record_r03.py gpurun_out/pmc3_base_runs_1920x1080 gpurun_out/pmc3_base_tiles_1920x1080 gpurun_out/pmc3_base_runs_3840x2160 gpurun_out/pmc3_base_tiles_3840x2160 > $OUT/pmc_record.log 2>&1
-cp profiles/r03_pmc.json $OUT/r03_pmc.json
 head -6 $OUT/r03_1080p_kernel_stats_timed.csv $OUT/r03_4k_kernel_stats_timed.csv
 cat $OUT/r03_1080p_bench.json | cut -c1-600

@@ -5,8 +5,9 @@
  * a pixel is "flagged" (redone in fp64 by the kernel) when d < LOW; for every unflagged pixel p - 256 must equal the
  * reference's fp64, unfused, left-to-right value truncated to int (image_processing.c:104-106), and t must lie in
  * [256, 512) for EVERY pixel (the bit trick assumes that exponent).
- *     gcc -O2 -ffp-contract=off tools/colour_fast_proof.c -o build/colour_fast_proof -lm && build/colour_fast_proof
+ *     gcc -O2 -ffp-contract=off -frounding-math tools/colour_fast_proof.c -o build/colour_fast_proof -lm && build/colour_fast_proof [down]
  */
+#include <fenv.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -15,7 +16,10 @@
 #define EPS 1.5e-4f
 #define LOW (10.0f / 32768.0f) /* kFracLow */
 
-int main(void) {
+int main(int argc, char **argv) {
+    /* "down": the three fmas rounded toward minus infinity (the encode kernels' pixel stage runs in that mode, fdct_f32.h);
+     * the reference's fp64 expression stays in round-to-nearest */
+    const int down = argc > 1 && strcmp(argv[1], "down") == 0;
     const double k0d[3] = {0.0, 128.0, 128.0};
     const double krd[3] = {0.299, -0.168736, 0.5}, kgd[3] = {0.587, -0.331264, -0.418688}, kbd[3] = {0.114, 0.5, -0.081312};
     const float krf[3] = {0.299f, -0.168736f, 0.5f}, kgf[3] = {0.587f, -0.331264f, -0.418688f},
@@ -30,11 +34,13 @@ int main(void) {
                     acc = acc + kgd[c] * (double)g;
                     acc = acc + kbd[c] * (double)b;
                     int want = (int)acc;
-                    float t = fmaf((float)b, kbf[c], k0);
+                    if (down) fesetround(FE_DOWNWARD);
+                    volatile float t = fmaf((float)b, kbf[c], k0);
                     t = fmaf((float)g, kgf[c], t);
                     t = fmaf((float)r, krf[c], t);
+                    if (down) fesetround(FE_TONEAREST);
                     uint32_t bits;
-                    memcpy(&bits, &t, 4);
+                    { float tt = t; memcpy(&bits, &tt, 4); }
                     bits &= 0xffff8000u;
                     float p;
                     memcpy(&p, &bits, 4);

@@ -40,6 +40,15 @@ static inline int to_int(Chk a) {
     if (a.v != floor(a.v)) { printf("to_int of a non-integer %.17g\n", a.v); g_inexact++; }
     return (int)a.v;
 }
+// fdct_row_f<F, true>: the product taken in round-toward-minus-infinity mode = the exact product, rounded down to fp32
+static inline Chk mul_down(Chk a, Chk k) {
+    const double r = a.v * k.v;
+    float f = (float)r;
+    if ((double)f > r) f = nextafterf(f, -INFINITY);
+    Chk c;
+    c.v = f;
+    return c;
+}
 } // namespace m1vf
 #include "fdct_f32.h"
 
@@ -81,13 +90,13 @@ static void fdct_int(const unsigned char px[64], int out[64]) {
     }
 }
 
-template <typename F>
+template <typename F, bool DOWN>
 static void fdct_f(const unsigned char px[64], double out[64], double (*val)(F)) {
     F rows[64];
     for (int i = 0; i < 8; i++) {
         F p[8];
         for (int j = 0; j < 8; j++) p[j] = F(m1vf::kPxBiasF + (float)px[i * 8 + j]);
-        m1vf::fdct_row_f<F>(p, &rows[i * 8]);
+        m1vf::fdct_row_f<F, DOWN>(p, &rows[i * 8]);
     }
     for (int i = 0; i < 8; i++) {
         F c[8];
@@ -102,14 +111,18 @@ static double val_c(Chk x) { return x.v; }
 static long long g_blocks = 0, g_wrong = 0;
 static void check(const unsigned char px[64]) {
     int want[64];
-    double got_f[64], got_c[64];
+    double got_f[64], got_c[64], got_fd[64], got_cd[64];
     fdct_int(px, want);
-    fdct_f<float>(px, got_f, val_f);
-    fdct_f<Chk>(px, got_c, val_c);
+    fdct_f<float, false>(px, got_f, val_f);   // both forms of the two (x * 181) >> 17 outputs (fdct_row_f)
+    fdct_f<Chk, false>(px, got_c, val_c);
+    fdct_f<float, true>(px, got_fd, val_f);
+    fdct_f<Chk, true>(px, got_cd, val_c);
     g_blocks++;
     for (int k = 0; k < 64; k++)
-        if (got_f[k] != (double)want[k] || got_c[k] != (double)want[k]) {
-            if (g_wrong < 10) printf("WRONG coefficient %d: int %d float %.9g checked %.9g\n", k, want[k], got_f[k], got_c[k]);
+        if (got_f[k] != (double)want[k] || got_c[k] != (double)want[k] || got_fd[k] != (double)want[k] || got_cd[k] != (double)want[k]) {
+            if (g_wrong < 10)
+                printf("WRONG coefficient %d: int %d float %.9g checked %.9g, rounded-down form %.9g checked %.9g\n", k, want[k], got_f[k], got_c[k],
+                       got_fd[k], got_cd[k]);
             g_wrong++;
         }
 }
