@@ -176,7 +176,7 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) { // 0 = Y, 1 = Cb, 2 = 
 constexpr float kEps = 1.5e-4f;
 struct CompCoefF {
     float k0, kr, kg, kb;
-    int comp;
+    CompCoef d; // the reference's fp64 coefficients of the same component, for the pixels the fp32 form cannot decide
 };
 __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     CompCoefF c;
@@ -184,7 +184,31 @@ __device__ __forceinline__ CompCoefF comp_coef_f(int comp) {
     c.kr = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
     c.kg = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
     c.kb = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
-    c.comp = comp;
+    c.d = comp_coef(comp);
+    return c;
+}
+// The same for a wave whose lanes all convert luma (first = true) or convert Cb in lanes 0-31 and Cr in lanes 32-63 (the
+// waves of a tile, m1v_tiles.h): a scalar branch and, on the chroma side, one select per register — a third of the vector
+// instructions the general three-way selects of comp_coef_f take per wave (12 registers; the fp64 ones are loop invariants
+// the compiler sets up in front of the rows either way).
+__device__ __forceinline__ CompCoefF comp_coef_wave(bool luma_wave, int lane) {
+    CompCoefF c;
+    if (luma_wave) {
+        asm volatile(""); // keeps the branch: two arms of selects would be merged back into three-way selects
+        c = comp_coef_f(0);
+    } else {
+        asm volatile("");
+        const CompCoefF cb = comp_coef_f(1), cr = comp_coef_f(2);
+        const bool hi = lane >= 32;
+        c.k0 = cb.k0;
+        c.kr = hi ? cr.kr : cb.kr;
+        c.kg = hi ? cr.kg : cb.kg;
+        c.kb = hi ? cr.kb : cb.kb;
+        c.d.k0 = cb.d.k0;
+        c.d.kr = hi ? cr.d.kr : cb.d.kr;
+        c.d.kg = hi ? cr.d.kg : cb.d.kg;
+        c.d.kb = hi ? cr.d.kb : cb.d.kb;
+    }
     return c;
 }
 
@@ -214,7 +238,7 @@ __device__ __forceinline__ float component_raw(uint32_t r, uint32_t g, uint32_t 
     const float t = component_t(r, g, b, k);
     float p = clear_fraction(t);
     if (t - p < kFracLow) {
-        CompCoef d = comp_coef(k.comp);
+        const CompCoef &d = k.d;
         p = m1vf::kPxBiasF + (float)component_fp64((int)r, (int)g, (int)b, d.k0, d.kr, d.kg, d.kb);
     }
     return p;
@@ -310,7 +334,7 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
             int byte = BPP * j + ch;
             return (w.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
         };
-        CompCoef d = comp_coef(k.comp);
+        const CompCoef &d = k.d;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t r = chan2(j, 0), gg = chan2(j, 1), b = chan2(j, 2);
@@ -629,10 +653,41 @@ __device__ __forceinline__ void frame_strip_of(unsigned b, int n_frames, int n_s
     }
 }
 
+// Division of a workgroup index by a launch constant without the compiler's float-reciprocal expansion (15 vector
+// instructions per division and wave): q = high half of n * m with m = floor(2^32 / d) + 1, exact while n * d < 2^32 — the
+// host checks that for the largest index of the launch and passes m = 0 (plain division) otherwise.  Scalar multiplies only.
+struct DivMagic {
+    uint32_t d, m;
+};
+M1V_HD DivMagic div_magic(uint32_t d, unsigned long long n_max) {
+    DivMagic r;
+    r.d = d;
+    r.m = (d >= 2 && n_max * d < (1ull << 32)) ? (uint32_t)((1ull << 32) / d) + 1u : 0u;
+    return r;
+}
+__device__ __forceinline__ uint32_t udiv(uint32_t n, const DivMagic &k) { return k.m ? __umulhi(n, k.m) : n / k.d; }
+// frame_strip_of with the launch's three divisors prepared: group = 8 * per_frame, per_frame
+__device__ __forceinline__ void frame_unit_of(uint32_t b, int n_frames, const DivMagic &group, const DivMagic &per_frame, int &frame,
+                                              int &unit) {
+    const uint32_t full = (uint32_t)n_frames / 8u;
+    if (b < full * group.d) {
+        const uint32_t gq = udiv(b, group), r = b - gq * group.d;
+        frame = (int)(gq * 8u + (r & 7u));
+        unit = (int)(r >> 3);
+    } else {
+        const uint32_t t = b - full * group.d, q = udiv(t, per_frame);
+        frame = (int)(full * 8u + q);
+        unit = (int)(t - q * per_frame.d);
+    }
+}
+
 #ifndef M1V_WAVES_PER_EU
 #define M1V_WAVES_PER_EU 5
 #endif
 #ifndef M1V_DENSE_KEEP
+#ifndef M1V_DENSE_DOWN
+#define M1V_DENSE_DOWN 0 // 1 = the run kernel rounds down too (experiment: measured slower, profiles/r03_ab_history.txt)
+#endif
 #define M1V_DENSE_KEEP 8 // row-pass outputs of the run kernels stay unpacked (RowStore)
 #endif
 
@@ -757,7 +812,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
             load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
         float ro[8];
-        m1vf::fdct_row_f<float, false>(px, ro);
+        m1vf::fdct_row_f<float, M1V_DENSE_DOWN != 0>(px, ro);
         rows.put(i, ro);
     }
     int dc = 0;
@@ -1041,7 +1096,11 @@ void k_encode_dense(DenseArgs a) {
 
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
+#if M1V_DENSE_DOWN
+    const uint8_t *fbase = pixel_stage_rounds_down(a.rgb + (unsigned long long)frame * g.frame_bytes, frame, run);
+#else
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
+#endif
     const unsigned long long run_index = (unsigned long long)frame * a.runs_per_frame + run;
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + run_index * a.slot_bytes); // compact slot (common case)
 
@@ -1664,7 +1723,6 @@ struct m1v_encoder {
     // hooks force (m1v_debug_set_path, a forced input mode, a forced run length).
     int forced_path;   // -1 = by geometry, 0 = runs, 1 = tiles
     int forced_T;      // run length forced by m1v_debug_set_dense_threads (0 = default)
-    bool prefer_tiles; // set (for good) by the first batch whose buffer is not 4-byte aligned
     bool tiles;        // the path configure_path set up
     int tile_cols, tile_rows, tiles_per_frame, tile_ring;
     uint32_t luma_region, chroma_region; // LDS bytes of a wave's ring / staging region
@@ -1789,13 +1847,11 @@ static int configure_path(m1v_encoder *e) {
         size_t arena_off;
         int image_words;
     } plan = {};
-    // Tiles by default wherever the run kernel cannot use its aligned 24-byte row loads (widths that are not a multiple of 8,
-    // buffers off a 4-byte boundary): there the tile kernel is 1.3-4x faster (profiles/r03_paths_by_geometry.txt).  On
-    // aligned pictures the two kernels run within 1-2 % of each other and the run kernel's gather is cheaper — unless the
-    // picture's top quarter (the source of every chroma block) outgrows an XCD's L2: the tile kernel then keeps the chroma
-    // re-reads in L2 by the order of its tile rows (tile_row_order_for), the run kernel re-fetches them from memory.
-    plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0) &&
-                 (e->forced_path == 1 || !e->fast_ok || e->prefer_tiles || g.frame_bytes / 4 > (3ull << 20));
+    // Tiles for every 3-channel picture: 1.3-4x faster than the run kernel where that cannot use its aligned 24-byte row loads
+    // (widths that are not a multiple of 8, buffers off a 4-byte boundary), 1 % faster at 4K (the order of the tile rows keeps
+    // the chroma re-reads in L2, tile_row_order_for), and 0.5-1 % faster per step on aligned 1080p in a sustained run
+    // (profiles/r03_ab_history.txt).  The run kernel serves 4-channel input and the m1v_debug_set_* hooks.
+    plan.tiles = g.C == 3 && e->forced_path != 0 && e->forced_mode < 0 && !(e->forced_path < 0 && dense_T > 0);
     size_t need, meta = 0, segb = 0;
     int segs = 0; // segments per strip
     if (plan.tiles) {
@@ -1810,6 +1866,7 @@ static int configure_path(m1v_encoder *e) {
         // LDS image of the tile's bits (192 blocks: ~115 words at quality 12 on noise), scaled with the quantiser like the
         // run kernels' (512 words per 256 blocks at quality <= 25) + the segments' word alignment and slice headers
         plan.image_words = e->lds_words > 0 ? e->lds_words : (e->qf <= 25 ? 400 : (e->qf <= 50 ? 784 : (e->qf <= 76 ? 1552 : 3088)));
+        plan.image_words = (plan.image_words + 3) & ~3; // cleared 16 bytes per lane
         plan.slot_bytes = (uint32_t)((((size_t)plan.image_words * 4 + 127) & ~(size_t)127) | 128);
         const size_t runs = (size_t)e->max_frames * plan.tiles_per_frame;
         plan.arena_slots = (uint32_t)(e->reserve_worst ? runs : (runs / 256 > 32 ? runs / 256 : (runs < 32 ? runs : 32)));
@@ -1974,7 +2031,6 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     e->forced_mode = -1;
     e->forced_path = -1;
     e->forced_T = 0;
-    e->prefer_tiles = false;
     e->tiles = false;
     e->tile_cols = e->tile_rows = e->tiles_per_frame = e->tile_ring = 0;
     e->luma_region = e->chroma_region = 0;
@@ -2237,15 +2293,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     if (n_frames < 0 || n_frames > e->max_frames) return fail(M1V_E_ARG, "n_frames exceeds max_frames%s");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(e->device));
-    if (!e->tiles && e->g.C == 3 && e->forced_path < 0 && e->forced_mode < 0 && e->forced_T == 0 && ((uintptr_t)d_rgb & 3) != 0) {
-        // a buffer off a 4-byte boundary would send the run kernel to its byte loads: from now on this encoder uses tiles
-        // (one reconfiguration: the device is drained and the scratch of the other kernel allocated)
-        HIP_TRY(hipDeviceSynchronize());
-        for (m1v_encoder::Batch &b : e->batch) b.gather_pending = false;
-        e->prefer_tiles = true;
-        const int rc = configure_path(e);
-        if (rc != M1V_OK) return rc;
-    }
     m1v_encoder::Batch &bt = e->batch[e->pipelined ? (e->calls++ & 1u) : 0];
     hipStream_t gs = e->pipelined ? e->side : st;   // stream of the layout + gather kernels
     if (e->pipelined && bt.gather_pending)           // this set's previous gather must have drained its scratch
@@ -2289,6 +2336,12 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.tile_cols = e->tile_cols;
         a.tile_rows = e->tile_rows;
         a.tiles_per_frame = e->tiles_per_frame;
+        {
+            const unsigned long long units = (unsigned long long)n_frames * (unsigned long long)e->tiles_per_frame;
+            a.div_group = div_magic(8u * (uint32_t)e->tiles_per_frame, units);
+            a.div_frame = div_magic((uint32_t)e->tiles_per_frame, units);
+            a.div_cols = div_magic((uint32_t)e->tile_cols, (unsigned long long)e->tiles_per_frame);
+        }
         a.tile_row_order = e->d_tile_order;
         a.lds_words = e->image_words;
         a.run_cap = e->run_cap;

@@ -47,6 +47,7 @@ struct TileArgs {
     uint32_t *status;
     int n_frames;
     int tile_cols, tile_rows, tiles_per_frame;
+    DivMagic div_group, div_frame, div_cols; // 8 * tiles_per_frame, tiles_per_frame, tile_cols (udiv)
     const uint32_t *tile_row_order; // [tile_rows] (32-bit: a scalar load): which tile row the k-th group of tile_cols workgroups of a frame takes
     int lds_words;          // capacity of the LDS image of the tile's bits
     uint32_t run_cap;       // bytes of one arena slot: the worst case of a tile
@@ -113,8 +114,17 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
     return dc;
 }
 
+// Row-pass outputs stay unpacked (RowStore<8>: 64 registers, 96 VGPRs = 5 waves per SIMD).  Packing them as f16 pairs
+// (RowStore<0>: 66 VGPRs, 6 waves per SIMD) wins 2 % while the launches come in bursts of a few and the chip boosts, and loses
+// 0.5-2.5 % in a sustained run, where the package sits at its 1400 W limit and the 96 extra conversions per block cost more
+// than the sixth wave hides (tools/sustained.py, profiles/r03_ab_history.txt).
 #ifndef M1V_TILE_KEEP
-#define M1V_TILE_KEEP 0
+#define M1V_TILE_KEEP 8
+#endif
+// the 16-bit staging of qualities above 76 needs a few registers more in the column stage: three column pairs packed there
+// (85 VGPRs; 4 unpacked columns already spill 40 bytes per lane)
+#ifndef M1V_TILE_KEEP_WIDE
+#define M1V_TILE_KEEP_WIDE 2
 #endif
 // Diagnostic build only (-DM1V_TILE_STAMPS, tools/tile_stamps.py): cycles a wave spends in each phase, kept in scalar
 // registers and added to TileArgs::stamps once at the end (a global atomic inside the row loop would join the vmcnt queue).
@@ -147,16 +157,16 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
 #define M1V_TILE_LEAN false
 #endif
 #ifndef M1V_TILE_WAVES_PER_EU
-#define M1V_TILE_WAVES_PER_EU 6
+#define M1V_TILE_WAVES_PER_EU 5
 #endif
 
 // The front half of a tile wave (shared by k_encode_tiles and k_coefficient_tiles): brings the wave's 64 blocks in through
 // its LDS ring and leaves the 64 row-pass outputs of the lane's block in `rows`.  `ring` = LDS byte address of the wave's
 // region; wave 0, 1 = luma, wave 2 = chroma (see the head of this file); `first` / `meanwhile`: see below.
-template <int R, typename First, typename Meanwhile>
+template <int R, int KEEP, typename First, typename Meanwhile>
 __device__ __forceinline__ void tile_pixel_rows(const Geometry &g, const uint8_t *fbase, uint32_t ring, int wave, int lane, int s0,
                                                 int m0, int strips_here, int comp, First first, Meanwhile meanwhile,
-                                                RowStore<M1V_TILE_KEEP> &rows) {
+                                                RowStore<KEEP> &rows) {
     const bool chroma = wave == 2;
     // ---- the lane's share of the wave's DMA.  One row-step = TWO 1-KiB LDS-DMA instructions into a 2-KiB ring slot, the
     //      same for the luma waves and the chroma wave (no branch, no EXEC mask, one vmcnt count):
@@ -214,7 +224,8 @@ __device__ __forceinline__ void tile_pixel_rows(const Geometry &g, const uint8_t
     meanwhile();
 
     // ---- rows out of the ring as they land, the freed slot refilled with row i + R ----
-    const CompCoefF kf = comp_coef_f(comp);
+    (void)comp;
+    const CompCoefF kf = comp_coef_wave(!chroma, lane);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int newest = (i - 1 + R < 7) ? (i - 1 + R) : 7; // newest row-step requested so far
@@ -250,10 +261,10 @@ void k_encode_tiles(TileArgs a) {
     uint32_t *image = lds + kTileFixedWords + (2u * a.luma_region + a.chroma_region) / 4u;
 
     int frame, tile;
-    frame_strip_of(blockIdx.x, a.n_frames, a.tiles_per_frame, frame, tile);
+    frame_unit_of(blockIdx.x, a.n_frames, a.div_group, a.div_frame, frame, tile);
     // Tile rows are taken in an order that keeps the chroma quirk's re-reads in L2 (tile_row_order_for): the tile's position
     // in that order only decides WHEN it runs; everything it writes is indexed by the tile row itself.
-    const int tk = tile / a.tile_cols, tc = tile - tk * a.tile_cols;
+    const int tk = (int)udiv((uint32_t)tile, a.div_cols), tc = tile - tk * a.tile_cols;
     const int tr = (int)a.tile_row_order[tk];
     tile = tr * a.tile_cols + tc;
     int s0 = tc * kTileStrips, m0 = tr * kTileMbRows;
@@ -285,8 +296,9 @@ void k_encode_tiles(TileArgs a) {
     //      first rows travel (it is first touched in pass 2, behind the barrier of the bit counts) ----
     TSTAMP_INIT();
     const uint32_t ring = lds0 + region_off; // LDS byte address of this wave's region
-    RowStore<M1V_TILE_KEEP> rows;
-    tile_pixel_rows<R>(
+    constexpr int kKeep = STAGE8 ? M1V_TILE_KEEP : M1V_TILE_KEEP_WIDE;
+    RowStore<kKeep> rows;
+    tile_pixel_rows<R, kKeep>(
         g, fbase, ring, wave, lane, s0, m0, strips_here, comp,
         [&]() {
 #pragma unroll
@@ -294,7 +306,8 @@ void k_encode_tiles(TileArgs a) {
                 dma4((uint32_t)lane * 4u, lds0 + (uint32_t)(kTileVlc + wave * kVlcWords + q * kWave) * 4u, a.tab->vlc + q * kWave);
         },
         [&]() {
-            for (int k = tid; k < a.lds_words; k += kTileThreads) image[k] = 0;
+            uint4 *image4 = reinterpret_cast<uint4 *>(image); // 16-byte aligned, a.lds_words % 4 == 0 (configure_path)
+            for (int k = tid; k < (a.lds_words >> 2); k += kTileThreads) image4[k] = make_uint4(0u, 0u, 0u, 0u);
         },
         rows);
     const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));
@@ -312,7 +325,7 @@ void k_encode_tiles(TileArgs a) {
     uint32_t *blkp = lds + region_off / 4u + lane * kStride;
     uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)blkp;
     TSTAMP(2);
-    const int dc = columns_to_stage<STAGE8, M1V_TILE_KEEP>(rows, rq_t, lds_addr);
+    const int dc = columns_to_stage<STAGE8, kKeep>(rows, rq_t, lds_addr);
     const unsigned long long nz = (stage_nonzero_mask<STAGE8>(blkp, lds_addr) & ~1ull) | (dc != 0 ? 1ull : 0ull);
     TSTAMP(3);
 
@@ -444,7 +457,7 @@ void k_coefficient_tiles(CoefTileArgs a) {
     const int comp = wave == 2 ? 1 + (lane >> 5) : 0;
 
     RowStore<M1V_TILE_KEEP> rows;
-    tile_pixel_rows<R>(g, fbase, lds0 + (uint32_t)wave * a.region, wave, lane, s0, m0, strips_here, comp, [] {}, [] {}, rows);
+    tile_pixel_rows<R, M1V_TILE_KEEP>(g, fbase, lds0 + (uint32_t)wave * a.region, wave, lane, s0, m0, strips_here, comp, [] {}, [] {}, rows);
 
     // column pass + quantise; level of zigzag position p -> int16 p of the lane's staged block (the ring is drained: its bytes are reused)
     const M1V_CONST_AS float *rq_t = reinterpret_cast<const M1V_CONST_AS float *>(reinterpret_cast<uintptr_t>(a.tab->rq_t));

@@ -212,8 +212,8 @@ def test_tile_kernel_shape_of_round_3(built):
     * the ring is two row-steps deep and every row is read as soon as ITS two instructions have landed: the vmcnt waits
       of the row loop are 2, 2, 2, 2, 2, 2, 2, 0 (one wait per row, no branch between the wave kinds);
     * the waves of a tile meet twice on the common path (bit counts, image complete);
-    * 72 VGPRs or fewer (7 waves per SIMD by registers; LDS admits 8 tiles = 6 waves per SIMD) and NO scratch: a spill
-      would also join the vmcnt queue the row loop counts on;
+    * 96 VGPRs or fewer (5 waves per SIMD: the row-pass outputs stay unpacked, m1v_tiles.h M1V_TILE_KEEP) and NO scratch: a
+      spill would also join the vmcnt queue the row loop counts on;
     * every LDS read issued from inline asm has its s_waitcnt in the same statement (nothing can sit between them)."""
     asm, notes = _gfx950_disassembly()
     for variant in ("k_encode_tilesILb1", "k_encode_tilesILb0"):
@@ -242,7 +242,7 @@ def test_tile_kernel_shape_of_round_3(built):
     recs = re.findall(r"\.name:\s*(\S*k_encode_tiles\S*).*?\.private_segment_fixed_size:\s*(\d+).*?\.vgpr_count:\s*(\d+)", notes, re.S)
     assert len(recs) == 2, recs
     for nm, scratch, vgprs in recs:
-        assert int(scratch) == 0 and int(vgprs) <= 72, (nm, scratch, vgprs)
+        assert int(scratch) == 0 and int(vgprs) <= 96, (nm, scratch, vgprs)
 
 
 def test_rounding_mode_of_the_pixel_stage(built):

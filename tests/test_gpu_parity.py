@@ -188,13 +188,14 @@ def test_host_delivery_overlapped_with_the_next_encode(torch_cuda, orc):
     enc.close()
 
 
-def test_path_is_picked_by_geometry_and_alignment(torch_cuda, orc):
-    """Aligned 3-channel pictures (width % 8 == 0, 4-byte aligned buffer) take the run kernel, every other 3-channel
-    input the tile kernel; an encoder that meets a misaligned buffer switches to tiles for good.  Same bytes either way."""
+def test_path_policy(torch_cuda, orc):
+    """Every 3-channel picture takes the tile kernel, whatever its width and the alignment of its buffer; 4-channel input and
+    the run kernel's tuning hooks (a forced run length or input mode) take the run kernel; m1v_debug_set_path overrides.
+    Same bytes either way."""
     torch = torch_cuda
-    for W, want_path in ((352, "runs"), (356, "tiles"), (350, "tiles")):
+    for W in (352, 356, 350):
         enc = _enc(W, 288, max_frames=2)
-        assert enc.path == want_path, (W, enc.path)
+        assert enc.path == "tiles", (W, enc.path)
         enc.close()
     enc4 = _enc(352, 288, channels=4, max_frames=2)
     assert enc4.path == "runs"
@@ -204,11 +205,17 @@ def test_path_is_picked_by_geometry_and_alignment(torch_cuda, orc):
     want, _ = orc.encode_frames(rgb, n, W, H, 0, 12, orc.MODE_FULL)
     flat = torch.empty(rgb.size + 16, dtype=torch.uint8, device="cuda")
     enc = _enc(W, H, max_frames=n)
-    for shift, path_after in ((0, "runs"), (2, "tiles"), (0, "tiles")):
+    for shift, forced, path_after in ((0, None, "tiles"), (2, None, "tiles"), (0, "runs", "runs"), (2, "runs", "runs"), (0, "auto", "tiles")):
+        if forced:
+            enc.debug_set_path(forced)
         dev = flat[shift:shift + rgb.size].view(n, H, W, 3)
         dev.copy_(torch.from_numpy(rgb))
         got, _ = enc.encode_to_bytes(dev, 0)
-        assert got == want and enc.path == path_after, (shift, enc.path)
+        assert got == want and enc.path == path_after, (shift, forced, enc.path)
+    enc.debug_set_input_mode(0)      # a forced input mode is a run-kernel hook
+    assert enc.path == "runs"
+    got, _ = enc.encode_to_bytes(flat[:rgb.size].view(n, H, W, 3), 0)
+    assert got == want
     enc.close()
 
 
