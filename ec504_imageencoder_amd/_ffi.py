@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libencoder.so")
+# EC504_LIBENCODER: a library variant (tools/mkvariant.sh) instead of the in-tree build, for the tuning tools
+LIB_PATH = os.environ.get("EC504_LIBENCODER") or os.path.join(PKG_DIR, "libencoder.so")
 
 MODE_STRICT, MODE_FULL = 0, 1
 OK, E_ARG, E_UNENCODABLE, E_NOSPACE, E_HIP, E_NODEVICE, E_SCRATCH = 0, -1, -2, -3, -4, -5, -6

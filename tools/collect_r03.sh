@@ -29,13 +29,13 @@ cp profiles/r03_pmc.json $OUT/r03_pmc.json
 cd /tmp
 echo "== stats"
 stats 1080p 200
-stats 1080p_tiles 200 --path tiles
+stats 1080p_runs 200 --path runs
 stats 4k 60 --width 3840 --height 2160 --steps 60 --warmup 20
 stats 4k_runs 60 --width 3840 --height 2160 --steps 60 --warmup 20 --path runs
 echo "== plain bench"
 cd $ROOT
 python3 bench.py > $OUT/r03_1080p_bench.json 2> /dev/null
-python3 bench.py --path tiles --no-cpu-baseline > $OUT/r03_1080p_tiles_bench.json 2> /dev/null
+python3 bench.py --path runs --no-cpu-baseline > $OUT/r03_1080p_runs_bench.json 2> /dev/null
 python3 bench.py --no-cpu-baseline --width 3840 --height 2160 --steps 60 --warmup 20 > $OUT/r03_4k_bench.json 2> /dev/null
 python3 bench.py --no-cpu-baseline --width 3840 --height 2160 --steps 60 --warmup 20 --path runs > $OUT/r03_4k_runs_bench.json 2> /dev/null
 head -6 $OUT/r03_1080p_kernel_stats_timed.csv $OUT/r03_4k_kernel_stats_timed.csv
