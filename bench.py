@@ -12,8 +12,8 @@ grouped send/recv to rank 0 over RCCL; --gather host: every rank copies its bits
 of one pinned host buffer), one host wait per step on eight pinned bytes per rank, nothing allocated
 inside the loop.  Rank 0 prints ONE JSON line.
 
-The line's `roofline` prices the dominant kernel (k_encode_dense on aligned 1080p, k_encode_tiles on pictures whose top
-quarter outgrows L2 and on unaligned input; --path forces one) against HBM with its time from HIP events recorded on
+The line's `roofline` prices the dominant kernel (k_encode_tiles for 3-channel input, k_encode_dense otherwise; --path
+forces one) against HBM with its time from HIP events recorded on
 the launch stream inside the library (per launch: min / median / max), carries the HBM bytes of the committed PMC
 passes (`traffic`, `pmc_fresh`), and says what the time is made of (`binding`, `valu`): see DESIGN.md, "Where the
 time goes".  `host_delivery`: the same steps with every batch's records delivered to pinned host memory under the
@@ -403,7 +403,7 @@ def main():
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
                          "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,
                          "kernel_ms_max": round(max(kernel_times), 4) if kernel_times else None, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "vector-ALU issue (~0.8 of the kernel time; two-slot instructions included the VALU is ~0.9 busy): neither kernel waits for HBM (frames resident in the Infinity Cache run no faster)",
+                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "package power: a sustained run holds the 1400 W cap at ~2.1-2.3 of 2.4 GHz (profiles/r03_power_trace.txt), so the kernel is timed by the energy of its vector instructions (~0.8 of the kernel time is VALU issue); neither kernel waits for HBM (frames resident in the Infinity Cache run no faster)",
                          "valu": valu_roofline(pmc, k_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
