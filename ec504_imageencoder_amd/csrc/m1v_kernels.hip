@@ -226,7 +226,11 @@ __device__ __forceinline__ CompCoefF comp_coef_wave(bool luma_wave, int lane) {
 // instruction) and compared once per row.  Raw pixels keep their bias through the FDCT: every multiplier input of the
 // butterflies is a difference (bias cancels), only the DC sum carries 64 * kPxBiasF, removed in fdct_col_f.
 // Proof over all 2^24 triples x 3 components: tools/colour_fast_proof.c (host) and the GPU tests.
+#ifdef M1V_TIMING_NO_TIES // timing build only (wrong bytes on the 0.1-0.2 % of pixels that need the fp64 form): what the tie path costs
+constexpr float kFracLow = -1.0f;
+#else
 constexpr float kFracLow = 10.0f / 32768.0f;
+#endif
 __device__ __forceinline__ float component_t(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
     float t = fmaf((float)b, k.kb, k.k0);
     t = fmaf((float)g, k.kg, t);

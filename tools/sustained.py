@@ -23,6 +23,7 @@ ap.add_argument("--n", type=int, default=300)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--settle", type=int, default=500)
 ap.add_argument("--launches", type=int, default=500)
+ap.add_argument("--nocheck", action="store_true", help="timing builds: do not compare the outputs")
 a = ap.parse_args()
 import torch
 
@@ -107,7 +108,7 @@ for r in range(a.rounds):
             digest = hash(out[:tot].cpu().numpy().tobytes())
             if ref is None:
                 ref = (tot, digest)
-            assert (tot, digest) == ref, f"{nm}: output differs from {a.names[0]}"
+            assert a.nocheck or (tot, digest) == ref, f"{nm}: output differs from {a.names[0]}"
 base = statistics.median(x[0] for x in res[a.names[0]])
 for nm in a.names:
     k = statistics.median(x[0] for x in res[nm])
