@@ -226,11 +226,7 @@ __device__ __forceinline__ CompCoefF comp_coef_wave(bool luma_wave, int lane) {
 // instruction) and compared once per row.  Raw pixels keep their bias through the FDCT: every multiplier input of the
 // butterflies is a difference (bias cancels), only the DC sum carries 64 * kPxBiasF, removed in fdct_col_f.
 // Proof over all 2^24 triples x 3 components: tools/colour_fast_proof.c (host) and the GPU tests.
-#ifdef M1V_TIMING_NO_TIES // timing build only (wrong bytes on the 0.1-0.2 % of pixels that need the fp64 form): what the tie path costs
-constexpr float kFracLow = -1.0f;
-#else
 constexpr float kFracLow = 10.0f / 32768.0f;
-#endif
 __device__ __forceinline__ float component_t(uint32_t r, uint32_t g, uint32_t b, const CompCoefF &k) {
     float t = fmaf((float)b, k.kb, k.k0);
     t = fmaf((float)g, k.kg, t);
@@ -250,9 +246,6 @@ __device__ __forceinline__ float component_raw(uint32_t r, uint32_t g, uint32_t 
 
 #define M1V_CONST_AS __attribute__((address_space(4)))
 
-#ifndef M1V_MIX_COLOUR
-#define M1V_MIX_COLOUR 0
-#endif
 
 // The tile kernels run their fp32 arithmetic rounded TOWARD MINUS INFINITY: fdct_row_f<float, true> takes two floors of
 // products that round (fdct_f32.h) and needs that mode; the colour sums are proven for it as well as for the default
@@ -283,42 +276,10 @@ __device__ __forceinline__ void convert_row(const RowT &v, const CompCoefF &k, f
         return (v.d[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
     };
     float lowest = 1.0f;
-#if M1V_MIX_COLOUR
-    // Byte -> float and the multiply-add in ONE instruction: a byte alone in a 16-bit half is the f16 denormal b * 2^-24, which
-    // v_fma_mix_f32 widens exactly; with the coefficient scaled by 2^24 (exact) the product is the same real number k * b, so
-    // the single rounding of the fma returns the bits of fmaf((float)b, k, acc).  Two fast instructions per register isolate
-    // its even bytes (& 0x00ff00ff) and three its odd ones (>> 8 first), against one conversion per byte.
-    constexpr int kRegs = (int)(sizeof(RowT) / 4);
-    uint32_t even[kRegs], odd[kRegs];
-#pragma unroll
-    for (int i = 0; i < kRegs; i++) {
-        even[i] = v.d[i] & 0x00ff00ffu;
-        odd[i] = (v.d[i] >> 8) & 0x00ff00ffu;
-    }
-    const float mr = k.kr * 16777216.0f, mg = k.kg * 16777216.0f, mb = k.kb * 16777216.0f;
-    auto mix = [&](int byte, float kk, float acc) -> float {
-        const uint32_t src = (byte & 1) ? odd[byte >> 2] : even[byte >> 2];
-        float r;
-        if (byte & 2)
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(src), "v"(kk), "v"(acc));
-        else
-            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(src), "v"(kk), "v"(acc));
-        return r;
-    };
-    auto component_mix = [&](int j) -> float {
-        float t = mix(BPP * j + 2, mb, k.k0);
-        t = mix(BPP * j + 1, mg, t);
-        return mix(BPP * j, mr, t);
-    };
-#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-#if M1V_MIX_COLOUR
-        const float t0 = component_mix(j), t1 = component_mix(j + 1);
-#else
         const float t0 = component_t(chan(j, 0), chan(j, 1), chan(j, 2), k);
         const float t1 = component_t(chan(j + 1, 0), chan(j + 1, 1), chan(j + 1, 2), k);
-#endif
         out[j] = clear_fraction(t0);
         out[j + 1] = clear_fraction(t1);
         lowest = fminf(fminf(lowest, t0 - out[j]), t1 - out[j + 1]);
@@ -689,9 +650,6 @@ __device__ __forceinline__ void frame_unit_of(uint32_t b, int n_frames, const Di
 #define M1V_WAVES_PER_EU 5
 #endif
 #ifndef M1V_DENSE_KEEP
-#ifndef M1V_DENSE_DOWN
-#define M1V_DENSE_DOWN 0 // 1 = the run kernel rounds down too (experiment: measured slower, profiles/r03_ab_history.txt)
-#endif
 #define M1V_DENSE_KEEP 8 // row-pass outputs of the run kernels stay unpacked (RowStore)
 #endif
 
@@ -816,7 +774,7 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
             load_row<false>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * (uint32_t)g.C), g.C, k, px);
         }
         float ro[8];
-        m1vf::fdct_row_f<float, M1V_DENSE_DOWN != 0>(px, ro);
+        m1vf::fdct_row_f<float, false>(px, ro); // default rounding mode: see pixel_stage_rounds_down
         rows.put(i, ro);
     }
     int dc = 0;
@@ -1100,11 +1058,7 @@ void k_encode_dense(DenseArgs a) {
 
     int frame, run;
     frame_strip_of(blockIdx.x, a.n_frames, a.runs_per_frame, frame, run);
-#if M1V_DENSE_DOWN
-    const uint8_t *fbase = pixel_stage_rounds_down(a.rgb + (unsigned long long)frame * g.frame_bytes, frame, run);
-#else
     const uint8_t *fbase = a.rgb + (unsigned long long)frame * g.frame_bytes;
-#endif
     const unsigned long long run_index = (unsigned long long)frame * a.runs_per_frame + run;
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + run_index * a.slot_bytes); // compact slot (common case)
 

@@ -336,11 +336,7 @@ void k_encode_tiles(TileArgs a) {
     BlockBits bb = {0, 0};
     dc_header(dc, blk < 4, blk, vlc, hdr, hlen);
     const unsigned long long emit = emit_set(nz);
-#if defined(M1V_TIMING_NO_PASS1) // timing build only (wrong bytes): what the code-word loop of pass 1 costs
-    bb.acc = ((unsigned long long)hdr << 2) | 2u;
-    bb.tot = hlen + 2;
-    (void)emit;
-#elif defined(M1V_TILE_PASS1_PAIRS)
+#if defined(M1V_TILE_PASS1_PAIRS)
     block_bits_pass1_pairs<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
 #else
     // one coefficient per trip: two per trip (half the dependent LDS round trips) is no faster in bursts and 1 % slower in a
