@@ -29,5 +29,5 @@ timeout -k 10 500 python3 bench.py --cli --frames 512 > $OUT/r03_cli_bench.json 
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 > $OUT/r03_n2_gloo_rehearsal_xgmi.json 2> /dev/null
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 2 --backend gloo --gather host --steps 20 --warmup 5 > $OUT/r03_n2_gloo_rehearsal_host.json 2> /dev/null
 echo "== fuzz"
-timeout -k 10 420 python3 tests/fuzz_parity.py 360 3032 > $OUT/fuzz_b.txt 2>&1; tail -1 $OUT/fuzz_b.txt
+timeout -k 10 300 python3 tests/fuzz_parity.py 240 3033 > $OUT/fuzz_b.txt 2>&1; tail -1 $OUT/fuzz_b.txt
 ls -la $OUT | head -30
