@@ -134,7 +134,9 @@ struct EncodeArgs {
     const uint8_t *rgb;
     const Tables *tab;
     uint8_t *scratch;           // [frame][strip][strip_cap]
-    uint32_t *strip_bytes;      // [frame][strip]
+    uint2 *seg;                 // [frame][strip]: (bits of the strip, where it starts in scratch: 4-byte words) — one segment per strip
+    unsigned long long *strip_ctr;   // [frame][strip]: bits of the strip
+    unsigned long long *frame_bytes; // [frame]: every strip adds its bytes (zero before the batch: k_assemble of the batch before)
     uint32_t *status;
     int n_frames;
     int threads;                // workgroup size
@@ -1009,7 +1011,12 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
         uint32_t nwords = (end_bits + 31) >> 5;
         for (uint32_t i = tid; i < nwords; i += T) slot32[i] = __builtin_bswap32(image[i]);
     }
-    if (tid == 0) a.strip_bytes[(unsigned long long)frame * g.n_strips + strip] = (end_bits + 7) >> 3;
+    if (tid == 0) {
+        const unsigned long long idx = (unsigned long long)frame * g.n_strips + strip;
+        a.seg[idx] = make_uint2(end_bits, (uint32_t)((idx * g.strip_cap) >> 2));
+        a.strip_ctr[idx] = end_bits;
+        atomicAdd(&a.frame_bytes[frame], (unsigned long long)((end_bits + 7) >> 3)); // zero bits pad the strip to a byte, encoder.h:442-443
+    }
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
 }
 
@@ -1222,93 +1229,9 @@ void k_encode_dense(DenseArgs a) {
 // ------------------------------------------------------------------------------------------------
 // layout + gather
 // ------------------------------------------------------------------------------------------------
-struct LayoutArgs {
-    const uint32_t *strip_bytes; // [frame][strip]
-    uint32_t *strip_off;         // [frame][strip] byte offset of the strip inside the frame payload
-    unsigned long long *frame_size;
-    unsigned long long *frame_off;
-    unsigned long long *out_frame_sizes; // may be null
-    unsigned long long *out_total;       // may be null
-    uint32_t *enc_status;                // status bits of the encode kernel; handed on and cleared by k_frame_offsets
-    uint32_t *out_status;                // the caller's status word (or a private sink): the gather ORs into it
-    uint32_t *arena_next;                // overflow-arena counter of the dense encode kernel, reset here for the next batch
-    int n_frames, n_strips;
-};
-
-__global__ __launch_bounds__(256) void k_frame_layout(LayoutArgs a) {
-    __shared__ uint32_t ws[32];
-    int f = blockIdx.x;
-    uint32_t run = 0;
-    for (int base = 0; base < a.n_strips; base += 256) {
-        int s = base + threadIdx.x;
-        uint32_t v = s < a.n_strips ? a.strip_bytes[(size_t)f * a.n_strips + s] : 0;
-        uint32_t tot;
-        uint32_t off = block_scan_exclusive(v, ws, 256, tot);
-        if (s < a.n_strips) a.strip_off[(size_t)f * a.n_strips + s] = run + off;
-        run += tot;
-    }
-    if (threadIdx.x == 0) a.frame_size[f] = 44ull + run + 4ull;
-}
-
-__global__ __launch_bounds__(1024) void k_frame_offsets(LayoutArgs a) {
-    __shared__ unsigned long long wsum[17];
-    __shared__ unsigned long long carry;
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < a.n_frames; base += 1024) {
-        int f = base + threadIdx.x;
-        unsigned long long v = f < a.n_frames ? a.frame_size[f] : 0, incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            unsigned long long o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long s = 0;
-            for (int w = 0; w < 16; w++) {
-                unsigned long long t = wsum[w];
-                wsum[w] = s;
-                s += t;
-            }
-            wsum[16] = s;
-        }
-        __syncthreads();
-        if (f < a.n_frames) {
-            a.frame_off[f] = carry + wsum[wave] + incl - v;
-            if (a.out_frame_sizes) a.out_frame_sizes[f] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry += wsum[16];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (a.out_total) *a.out_total = carry;
-        // status hand-over (saves a memset before and a copy after every batch): the encode kernel is complete, the
-        // gather has not started; the word is zero again for the next batch that uses this set of buffers
-        *a.out_status = *a.enc_status;
-        *a.enc_status = 0;
-        *a.arena_next = 0;
-    }
-}
-
-struct GatherArgs {
-    const uint8_t *scratch;
-    const uint32_t *strip_bytes, *strip_off;
-    const unsigned long long *frame_size, *frame_off;
-    const Tables *tab;
-    uint8_t *out;
-    unsigned long long out_cap;
-    uint32_t *status;
-    uint32_t strip_cap;
-    int n_frames, n_strips, first_index;
-};
-
 // PKT SEQ GOP PIC in front of a frame's strips with the 16-bit length back-patched (encoder.h:198-230, :448-453:
 // (u16)(bytes after the length field's word) - 4) and the four trailing bytes (encoder.h:456-458, observed zero);
-// threads 0..47 of the workgroup that gathers the frame's first strip
+// threads 0..47 of the workgroup that assembles the frame's first strips
 __device__ __forceinline__ void frame_header_and_trailer(const Tables *tab, uint8_t *out, unsigned long long fo,
                                                          unsigned long long fs, int index, int t) {
     if (t < 44) {
@@ -1322,22 +1245,9 @@ __device__ __forceinline__ void frame_header_and_trailer(const Tables *tab, uint
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
-    int s = blockIdx.x, f = blockIdx.y;
-    unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
-    if (fo + fs > a.out_cap) {
-        if (threadIdx.x == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
-        return;
-    }
-    size_t idx = (size_t)f * a.n_strips + s;
-    const uint8_t *src = a.scratch + idx * a.strip_cap;
-    uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
-    uint32_t n = a.strip_bytes[idx];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, (int)threadIdx.x);
-}
+#include "m1v_assemble.h"
 
-// ---- dense path: strips are concatenations of run segments ----------------------------------------
+// ---- run kernels: strips are concatenations of run segments ----------------------------------------
 struct DenseGeom {
     int n_frames, n_strips, bps, T, runs_per_frame;
 };
@@ -1355,57 +1265,32 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
     return m[1];
 }
 
-// One workgroup per frame: the run segments of every strip, in the form the gather takes them (k_gather_segments in
-// m1v_tiles.h): seg[frame][strip][q] = (bits, where), padded with empty segments up to `segs` per strip; then strip byte
-// counts and the exclusive scan of the strips.
+// One workgroup per frame: the run segments of every strip, in the form k_assemble takes them: seg[frame][strip][q] =
+// (bits, where), padded with empty segments up to `segs` per strip; the strips' bit totals; the frame's bytes.
 __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int segs, const uint32_t *run_meta, uint2 *seg,
-                                                            uint32_t *strip_bytes, uint32_t *strip_off,
-                                                            unsigned long long *frame_size) {
-    __shared__ uint32_t ws[32];
+                                                            unsigned long long *strip_ctr, unsigned long long *frame_bytes) {
+    __shared__ unsigned long long wsum[4];
     const int f = blockIdx.x;
     const uint32_t *mf = run_meta + (size_t)f * d.runs_per_frame * 4;
-    uint32_t run_total = 0;
-    for (int base = 0; base < d.n_strips; base += 256) {
-        const int s = base + threadIdx.x;
-        uint32_t nbytes = 0;
-        if (s < d.n_strips) {
-            const size_t i = (size_t)f * d.n_strips + s;
-            const int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T; // w_hi - w_lo + 1 <= segs
-            uint32_t bits = 0;
-            for (int q = 0; q < segs; q++) {
-                uint32_t boff = 0, L = 0;
-                if (w_lo + q <= w_hi) L = dense_segment(d, mf, w_lo + q, s, boff);
-                seg[i * segs + q] = make_uint2(L, boff);
-                bits += L;
-            }
-            nbytes = (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
-            strip_bytes[i] = nbytes;
+    unsigned long long bytes = 0;
+    for (int s = threadIdx.x; s < d.n_strips; s += 256) {
+        const size_t i = (size_t)f * d.n_strips + s;
+        const int w_lo = (s * d.bps) / d.T, w_hi = ((s + 1) * d.bps - 1) / d.T; // w_hi - w_lo + 1 <= segs
+        uint32_t bits = 0;
+        for (int q = 0; q < segs; q++) {
+            uint32_t boff = 0, L = 0;
+            if (w_lo + q <= w_hi) L = dense_segment(d, mf, w_lo + q, s, boff);
+            seg[i * segs + q] = make_uint2(L, boff);
+            bits += L;
         }
-        uint32_t tot;
-        uint32_t off = block_scan_exclusive(nbytes, ws, 256, tot);
-        if (s < d.n_strips) strip_off[(size_t)f * d.n_strips + s] = run_total + off;
-        run_total += tot;
+        strip_ctr[i] = bits;
+        bytes += (bits + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
     }
-    if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
+    bytes = wave_sum_u64(bytes);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = bytes;
+    __syncthreads();
+    if (threadIdx.x == 0) frame_bytes[f] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
-
-// 32 bits [lo_bit, lo_bit + 32) of a strip that is the concatenation of segments (src, bits): a 64-bit window of
-// the source segment (word loads from the word-aligned scratch), funnel-shifted to the destination phase.
-__device__ __forceinline__ uint32_t strip_bits_from(const uint8_t *seg_base, uint32_t D, uint32_t L, uint32_t lo_bit) {
-    uint32_t hi_bit = lo_bit + 32u;
-    uint32_t lo = max(lo_bit, D), hi = min(hi_bit, D + L);
-    if (lo >= hi) return 0u;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(seg_base);
-    uint32_t sb = lo - D, nb = hi - lo, wi = sb >> 5, sh = sb & 31u;
-    unsigned long long win = ((unsigned long long)__builtin_bswap32(src[wi]) << 32) | __builtin_bswap32(src[wi + 1]);
-    uint32_t bits = (uint32_t)((win << sh) >> (64u - nb));
-    return bits << (32u - (lo - lo_bit) - nb);
-}
-
-#ifndef M1V_GATHER_STRIPS
-#define M1V_GATHER_STRIPS 4
-#endif
-constexpr int kGatherStrips = M1V_GATHER_STRIPS; // strips (one wave each) per gather workgroup
 
 #include "m1v_tiles.h"
 
@@ -1689,16 +1574,24 @@ struct m1v_encoder {
     size_t meta_bytes, seg_bytes; // sizes of run_meta and seg in effect
     int segs;               // segments per strip: tile rows (tiles), or the most runs a strip can touch (run kernels)
     Tables *d_tab;
-    // Everything one batch owns between its encode kernel and the end of its gather.  Two sets, so that in
-    // pipelined mode batch k+1 can encode while batch k is still being gathered.
+    // What k_assemble needs to know about the output (configure_path): strips per workgroup, lanes per segment, LDS image
+    int asm_group, asm_lanes_log2, asm_img_words;
+    // What an encode kernel adds to and k_assemble reads.  Two sets per Batch, taken in turns: the assemble kernel of call j clears
+    // the set call j + 1 will add to (the one call j - 1 used), so no launch and no memset stands between two batches.
+    struct Counters {
+        unsigned long long *strip_ctr;   // [frame][strip] bits of the strip (tile kernel: + arrivals << 40)
+        unsigned long long *frame_bytes; // [frame] bytes of the frame's strips
+        uint32_t *words;                 // [0] status bits of the encode kernel, [1] sink for callers without a status word, [2] arena counter
+        int dirty_frames;                // frames of the set's last batch that nobody has cleared yet
+    };
+    // Everything one batch owns between its encode kernel and the end of its assembly.  Two sets, so that in
+    // pipelined mode batch k+1 can encode while batch k is still being assembled.
     struct Batch {
         uint8_t *scratch;
         uint32_t *run_meta;     // run kernels: [frame][run][4]
         uint2 *seg;             // [frame][strip][segment] (bits, where): what a strip is concatenated from
-        uint32_t *strip_bits;   // tile kernel: bits of every strip, added up by the tiles (k_tile_layout reads and clears it)
-        uint32_t *strip_bytes, *strip_off;
-        unsigned long long *frame_size, *frame_off;
-        uint32_t *status;
+        Counters ctr[2];
+        unsigned turn;
         hipEvent_t enc_done, gather_done;
         bool gather_pending;
     } batch[2];
@@ -1742,7 +1635,7 @@ int m1v_warm_up(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr)); // creates the context
     hipFuncAttributes attr;    // loads this library's code object for the device
-    HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_frame_offsets)));
+    HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_assemble)));
     return M1V_OK;
 }
 
@@ -1859,6 +1752,23 @@ static int configure_path(m1v_encoder *e) {
         segs = (bps + T - 1) / T + 1; // the most runs whose blocks one strip can hold
     } else {
         need = (size_t)e->max_frames * g.n_strips * g.strip_cap;
+        if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
+        segs = 1; // a strip is one piece
+    }
+    // k_assemble (m1v_assemble.h): strips per workgroup so that a group's bytes fit its 16-KiB LDS image in one pass on noise at
+    // this quality (19 bits per block at quality 12; anything larger takes more passes), a power of two (the eight
+    // strips of a tile column share their scratch lines); lanes per segment ~ the words a segment holds.
+    int asm_group, asm_lanes_log2;
+    {
+        const int qscale = e->qf <= 25 ? 1 : (e->qf <= 50 ? 2 : (e->qf <= 76 ? 4 : 8));
+        const size_t bpb = 22u * (size_t)qscale;
+        const size_t strip_est = (38 + (size_t)g.n_mbrows * (2 + 6 * bpb)) / 8 + 1;
+        asm_group = 1;
+        while (asm_group < kAsmMaxGroup && (size_t)(2 * asm_group) * strip_est * 5 / 4 <= 16384 && 2 * asm_group <= g.n_strips) asm_group *= 2;
+        const size_t seg_blocks = plan.tiles ? (size_t)kTileSegBlocks : (e->dense ? (size_t)plan.dense_T : (size_t)bps);
+        const size_t seg_words = seg_blocks * bpb / 32;
+        asm_lanes_log2 = 2;
+        while (asm_lanes_log2 < 6 && ((size_t)1 << asm_lanes_log2) * 4 < seg_words * 3) asm_lanes_log2++;
     }
     const int sets = e->pipelined ? 2 : 1;
     segb = (size_t)e->max_frames * g.n_strips * segs * sizeof(uint2);
@@ -1902,18 +1812,21 @@ static int configure_path(m1v_encoder *e) {
             (void)hipFree(bt.seg);
             bt.seg = (uint2 *)f.seg;
         }
-        size_t nslots = (size_t)e->max_frames * g.n_strips;
-        if (!bt.strip_bytes) {
-            hipError_t err = hipMalloc(&bt.strip_bytes, nslots * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipMalloc(&bt.strip_off, nslots * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipMalloc(&bt.strip_bits, nslots * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipMemset(bt.strip_bits, 0, nslots * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipMalloc(&bt.frame_size, (size_t)e->max_frames * 8);
-            if (err == hipSuccess) err = hipMalloc(&bt.frame_off, (size_t)e->max_frames * 8);
-            if (err == hipSuccess) err = hipMalloc(&bt.status, 4 * sizeof(uint32_t)); // [0] encode status, [1] sink, [2] arena counter
-            if (err == hipSuccess) err = hipMemset(bt.status, 0, 4 * sizeof(uint32_t));
-            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
+        const size_t nslots = (size_t)e->max_frames * g.n_strips;
+        if (!bt.enc_done) {
+            hipError_t err = hipSuccess;
+            for (m1v_encoder::Counters &c : bt.ctr) {
+                if (err == hipSuccess) err = hipMalloc(&c.strip_ctr, nslots * 8);
+                if (err == hipSuccess) err = hipMemset(c.strip_ctr, 0, nslots * 8);
+                if (err == hipSuccess) err = hipMalloc(&c.frame_bytes, (size_t)e->max_frames * 8);
+                if (err == hipSuccess) err = hipMemset(c.frame_bytes, 0, (size_t)e->max_frames * 8);
+                if (err == hipSuccess) err = hipMalloc(&c.words, 4 * sizeof(uint32_t));
+                if (err == hipSuccess) err = hipMemset(c.words, 0, 4 * sizeof(uint32_t));
+                c.dirty_frames = 0;
+            }
+            bt.turn = 0;
             if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.gather_done, hipEventDisableTiming);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
             if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
         }
     }
@@ -1939,6 +1852,9 @@ static int configure_path(m1v_encoder *e) {
     e->meta_bytes = meta ? meta : e->meta_bytes; // (a path without run metadata keeps the other path's array and its size)
     e->seg_bytes = segb ? segb : e->seg_bytes;
     e->segs = segs;
+    e->asm_group = asm_group;
+    e->asm_lanes_log2 = asm_lanes_log2;
+    e->asm_img_words = 4096;
     return M1V_OK;
 }
 
@@ -2054,12 +1970,11 @@ void m1v_destroy(m1v_encoder *e) {
         (void)hipFree(bt.scratch);
         (void)hipFree(bt.run_meta);
         (void)hipFree(bt.seg);
-        (void)hipFree(bt.strip_bits);
-        (void)hipFree(bt.strip_bytes);
-        (void)hipFree(bt.strip_off);
-        (void)hipFree(bt.frame_size);
-        (void)hipFree(bt.frame_off);
-        (void)hipFree(bt.status);
+        for (m1v_encoder::Counters &c : bt.ctr) {
+            (void)hipFree(c.strip_ctr);
+            (void)hipFree(c.frame_bytes);
+            (void)hipFree(c.words);
+        }
         if (bt.enc_done) (void)hipEventDestroy(bt.enc_done);
         if (bt.gather_done) (void)hipEventDestroy(bt.gather_done);
     }
@@ -2262,21 +2177,11 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
     }
     const Geometry &g = e->g;
     const bool fast = fast_path(e, d_rgb);
-    LayoutArgs l;
-    l.strip_bytes = bt.strip_bytes;
-    l.strip_off = bt.strip_off;
-    l.frame_size = bt.frame_size;
-    l.frame_off = bt.frame_off;
-    l.out_frame_sizes = (unsigned long long *)d_frame_sizes;
-    l.out_total = (unsigned long long *)d_total;
-    l.enc_status = bt.status;
-    l.out_status = d_status ? d_status : bt.status + 1;
-    l.arena_next = bt.status + 2;
-    l.n_frames = n_frames;
-    l.n_strips = g.n_strips;
-
-    if (!bt.scratch || ((e->tiles || e->dense) && !bt.seg) || (!e->tiles && e->dense && !bt.run_meta))
+    if (!bt.scratch || !bt.seg || (!e->tiles && e->dense && !bt.run_meta))
         return fail(M1V_E_HIP, "the encoder has no scratch (an earlier allocation failed)%s");
+    // the counters this batch adds to, and the set the next batch of this Batch will use (k_assemble clears it)
+    m1v_encoder::Counters &cur = bt.ctr[bt.turn & 1u], &nxt = bt.ctr[(bt.turn + 1u) & 1u];
+    bt.turn++;
     if (e->tiles) {
         TileArgs a;
         a.g = g;
@@ -2284,12 +2189,13 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.tab = e->d_tab;
         a.scratch = bt.scratch;
         a.seg = bt.seg;
-        a.strip_bits = bt.strip_bits;
-        a.arena_next = bt.status + 2;
+        a.strip_ctr = cur.strip_ctr;
+        a.frame_bytes = cur.frame_bytes;
+        a.arena_next = cur.words + 2;
         a.slot_bytes = e->slot_bytes;
         a.arena_slots = e->arena_slots;
         a.arena_off = e->arena_off;
-        a.status = bt.status;
+        a.status = cur.words;
         a.n_frames = n_frames;
         a.tile_cols = e->tile_cols;
         a.tile_rows = e->tile_rows;
@@ -2320,28 +2226,6 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             HIP_TRY(hipEventRecord(bt.enc_done, st));
             HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
         }
-        SegGeom d;
-        d.n_frames = n_frames;
-        d.n_strips = g.n_strips;
-        d.segs = e->tile_rows;
-        hipLaunchKernelGGL(k_tile_layout, dim3(n_frames), dim3(256), 0, gs, d, bt.strip_bits, bt.strip_bytes, bt.strip_off, bt.frame_size);
-        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
-        SegGatherArgs ga;
-        ga.d = d;
-        ga.scratch = bt.scratch;
-        ga.seg = bt.seg;
-        ga.strip_bytes = bt.strip_bytes;
-        ga.strip_off = bt.strip_off;
-        ga.frame_size = bt.frame_size;
-        ga.frame_off = bt.frame_off;
-        ga.tab = e->d_tab;
-        ga.out = d_out;
-        ga.out_cap = out_cap;
-        ga.status = d_status ? d_status : bt.status + 1;
-        ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
-                           (size_t)kGatherStrips * (3 * e->tile_rows + 1 + 4 * kWave) * sizeof(uint32_t), gs, ga);
-        HIP_TRY(hipGetLastError());
     } else if (e->dense) {
         DenseArgs a;
         a.g = g;
@@ -2349,7 +2233,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.tab = e->d_tab;
         a.scratch = bt.scratch;
         a.run_meta = bt.run_meta;
-        a.status = bt.status;
+        a.status = cur.words;
         a.n_frames = n_frames;
         a.threads = e->dense_T;
         a.runs_per_frame = e->runs_per_frame;
@@ -2361,7 +2245,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.slot_bytes = e->slot_bytes;
         a.arena_slots = e->arena_slots;
         a.arena_off = e->arena_off;
-        a.arena_next = bt.status + 2;
+        a.arena_next = cur.words + 2;
         a.stamps = e->d_stamps;
         const int stride = e->narrow ? kStageStride8 : kStageStride16;
         a.zero_iters = (a.lds_words + e->dense_T - 1) / e->dense_T;
@@ -2403,26 +2287,8 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         d.bps = g.n_mbrows * 6;
         d.T = e->dense_T;
         d.runs_per_frame = e->runs_per_frame;
-        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, e->segs, bt.run_meta, bt.seg, bt.strip_bytes,
-                           bt.strip_off, bt.frame_size);
-        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
-        SegGatherArgs ga;
-        ga.d.n_frames = n_frames;
-        ga.d.n_strips = g.n_strips;
-        ga.d.segs = e->segs;
-        ga.scratch = bt.scratch;
-        ga.seg = bt.seg;
-        ga.strip_bytes = bt.strip_bytes;
-        ga.strip_off = bt.strip_off;
-        ga.frame_size = bt.frame_size;
-        ga.frame_off = bt.frame_off;
-        ga.tab = e->d_tab;
-        ga.out = d_out;
-        ga.out_cap = out_cap;
-        ga.status = d_status ? d_status : bt.status + 1;
-        ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather_segments, dim3((g.n_strips + kGatherStrips - 1) / kGatherStrips, n_frames), dim3(kWave * kGatherStrips),
-                           (size_t)kGatherStrips * (3 * e->segs + 1 + 4 * kWave) * sizeof(uint32_t), gs, ga);
+        hipLaunchKernelGGL(k_dense_frame_layout, dim3(n_frames), dim3(256), 0, gs, d, e->segs, bt.run_meta, bt.seg, cur.strip_ctr,
+                           cur.frame_bytes);
         HIP_TRY(hipGetLastError());
     } else {
         EncodeArgs a;
@@ -2430,8 +2296,10 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         a.rgb = d_rgb;
         a.tab = e->d_tab;
         a.scratch = bt.scratch;
-        a.strip_bytes = bt.strip_bytes;
-        a.status = bt.status;
+        a.seg = bt.seg;
+        a.strip_ctr = cur.strip_ctr;
+        a.frame_bytes = cur.frame_bytes;
+        a.status = cur.words;
         a.n_frames = n_frames;
         a.threads = e->threads;
         a.lds_words = e->lds_words > 0 ? e->lds_words : kDefaultLdsWords;
@@ -2449,23 +2317,42 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
             HIP_TRY(hipEventRecord(bt.enc_done, st));
             HIP_TRY(hipStreamWaitEvent(gs, bt.enc_done, 0));
         }
-        hipLaunchKernelGGL(k_frame_layout, dim3(n_frames), dim3(256), 0, gs, l);
-        hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(1024), 0, gs, l);
-        GatherArgs ga;
+    }
+    // ---- frame offsets, strip offsets, concatenation, headers, sizes, status: one launch (m1v_assemble.h) ----
+    {
+        AssembleArgs ga;
+        ga.n_frames = n_frames;
+        ga.n_strips = g.n_strips;
+        ga.segs = e->segs;
+        ga.group = e->asm_group;
+        ga.lanes_log2 = e->asm_lanes_log2;
+        ga.img_words = e->asm_img_words;
+        ga.div_segs = div_magic((uint32_t)e->segs, (unsigned long long)e->asm_group * (unsigned long long)e->segs);
         ga.scratch = bt.scratch;
-        ga.strip_bytes = bt.strip_bytes;
-        ga.strip_off = bt.strip_off;
-        ga.frame_size = bt.frame_size;
-        ga.frame_off = bt.frame_off;
+        ga.seg = bt.seg;
+        ga.strip_ctr = cur.strip_ctr;
+        ga.frame_bytes = cur.frame_bytes;
+        ga.enc_words = cur.words;
+        ga.next_strip_ctr = nxt.strip_ctr;
+        ga.next_frame_bytes = nxt.frame_bytes;
+        ga.next_words = nxt.words;
+        if (nxt.dirty_frames > n_frames) { // a longer batch than this one used that set last: clear what this launch does not reach
+            HIP_TRY(hipMemsetAsync(nxt.strip_ctr, 0, (size_t)nxt.dirty_frames * g.n_strips * 8, gs));
+            HIP_TRY(hipMemsetAsync(nxt.frame_bytes, 0, (size_t)nxt.dirty_frames * 8, gs));
+            nxt.dirty_frames = 0;
+        }
+        ga.next_frames = nxt.dirty_frames;
+        nxt.dirty_frames = 0;
+        cur.dirty_frames = n_frames;
         ga.tab = e->d_tab;
         ga.out = d_out;
         ga.out_cap = out_cap;
-        ga.status = d_status ? d_status : bt.status + 1;
-        ga.strip_cap = g.strip_cap;
-        ga.n_frames = n_frames;
-        ga.n_strips = g.n_strips;
+        ga.out_sizes = (unsigned long long *)d_frame_sizes;
+        ga.out_total = (unsigned long long *)d_total;
+        ga.out_status = d_status ? d_status : cur.words + 1;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_gather, dim3(g.n_strips, n_frames), dim3(256), 0, gs, ga);
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((g.n_strips + e->asm_group - 1) / e->asm_group), (unsigned)n_frames), dim3(kAsmThreads),
+                           (size_t)(e->asm_img_words + kAsmFixedWords) * sizeof(uint32_t), gs, ga);
         HIP_TRY(hipGetLastError());
     }
     if (e->pipelined) {

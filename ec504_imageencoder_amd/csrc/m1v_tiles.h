@@ -40,7 +40,10 @@ struct TileArgs {
     const Tables *tab;
     uint8_t *scratch;       // [frame][tile][slot_bytes] compact slots, then the overflow arena (as the run kernels)
     uint2 *seg;             // [frame][strip][tile row]: bits of the segment, where it starts (4-byte words from `scratch`)
-    uint32_t *strip_bits;   // [frame][strip]: every tile adds its segments' bits (zero before the batch: k_tile_layout clears it)
+    unsigned long long *strip_ctr;   // [frame][strip]: every tile adds (1 << 40 | its segment's bits) with ONE returning atomic: the tile
+                                     // that sees tile_rows - 1 arrivals in front of it completes the strip and knows its bits
+    unsigned long long *frame_bytes; // [frame]: that tile adds the strip's bytes (both zero before the batch: k_assemble of the batch
+                                     // before clears them)
     uint32_t *arena_next;
     uint32_t slot_bytes, arena_slots;
     unsigned long long arena_off;
@@ -377,6 +380,16 @@ void k_encode_tiles(TileArgs a) {
     TSTAMP(6);
 
     auto walk = [&](auto &sink) { walk_codes<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, sink); };
+    // The strip's bit total (wave 0, lanes < strips_here): one returning atomic per segment; the tile whose add finds every other
+    // tile row of the strip already counted knows the strip's bits and adds its bytes (zero bits pad a strip to a byte,
+    // encoder.h:442-443) to the frame's total.  Only the values the atomics return travel between tiles: no fence.
+    auto strip_arrives = [&](uint32_t bits) -> unsigned long long {
+        return atomicAdd(&a.strip_ctr[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], (1ull << kCtrCountShift) | (unsigned long long)bits);
+    };
+    auto strip_completes = [&](unsigned long long before, uint32_t bits) {
+        if ((uint32_t)(before >> kCtrCountShift) == (uint32_t)a.tile_rows - 1u)
+            atomicAdd(&a.frame_bytes[frame], ((before & kCtrBitsMask) + bits + 7ull) >> 3);
+    };
     uint2 *seg_out = a.seg + ((unsigned long long)frame * g.n_strips + (unsigned)(s0 + lane)) * a.tile_rows + tr; // lanes < strips_here
     auto slice_headers = [&](uint32_t *img, bool swapped) { // wave 0, lanes < strips_here
         if (tr == 0) {
@@ -393,7 +406,10 @@ void k_encode_tiles(TileArgs a) {
         const uint32_t got = misc[0];
         if (got >= a.arena_slots) { // arena exhausted: the caller re-encodes after m1v_reserve_scratch
             if (tid == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_SCRATCH);
-            if (wave == 0 && lane < strips_here) *seg_out = make_uint2(0u, 0u);
+            if (wave == 0 && lane < strips_here) {
+                *seg_out = make_uint2(0u, 0u);
+                strip_completes(strip_arrives(0u), 0u); // sizes stay consistent; the batch is flagged and encoded again
+            }
             return;
         }
         const unsigned long long where = a.arena_off + (unsigned long long)got * a.run_cap;
@@ -403,7 +419,7 @@ void k_encode_tiles(TileArgs a) {
         if (wave == 0 && lane < strips_here) {
             slice_headers(big, true);
             *seg_out = make_uint2(seg_bits, (uint32_t)(where >> 2) + (seg_incl - seg_words));
-            atomicAdd(&a.strip_bits[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], seg_bits);
+            strip_completes(strip_arrives(seg_bits), seg_bits);
         }
         if (valid) put_block<true>(big, off, bb, walk);
         if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
@@ -411,10 +427,11 @@ void k_encode_tiles(TileArgs a) {
     }
 
     // ---- common path: OR the bits into the LDS image, store it once to the tile's compact slot ----
+    unsigned long long arrived = 0; // requested here, looked at behind pass 2 and the store
     if (wave == 0 && lane < strips_here) {
         slice_headers(image, false);
         *seg_out = make_uint2(seg_bits, (uint32_t)((tile_index * a.slot_bytes) >> 2) + (seg_incl - seg_words));
-        atomicAdd(&a.strip_bits[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], seg_bits);
+        arrived = strip_arrives(seg_bits);
     }
     if (valid) put_block<false>(image, off, bb, walk);
     TSTAMP(7);
@@ -423,6 +440,7 @@ void k_encode_tiles(TileArgs a) {
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + tile_index * a.slot_bytes);
     for (uint32_t i = tid; i < end_words; i += kTileThreads) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
+    if (wave == 0 && lane < strips_here) strip_completes(arrived, seg_bits);
     TSTAMP(9);
     TSTAMP_FLUSH();
 }
@@ -499,147 +517,3 @@ void k_coefficient_tiles(CoefTileArgs a) {
     }
 }
 
-// ---- layout and gather for tiles: a strip is the concatenation of its tile_rows segments ---------------------------
-struct SegGeom {
-    int n_frames, n_strips, segs; // segs = segments per strip (tile rows here; k_dense_frame_layout pads to its own count)
-};
-
-// One workgroup per frame: strip byte counts from the bit totals the tiles added up (cleared here for the next batch),
-// exclusive scan of the strips.
-__global__ __launch_bounds__(256) void k_tile_layout(SegGeom d, uint32_t *strip_bits, uint32_t *strip_bytes, uint32_t *strip_off,
-                                                     unsigned long long *frame_size) {
-    __shared__ uint32_t ws[32];
-    const int f = blockIdx.x;
-    uint32_t run_total = 0;
-    for (int base = 0; base < d.n_strips; base += 256) {
-        const int s = base + threadIdx.x;
-        uint32_t nbytes = 0;
-        if (s < d.n_strips) {
-            const size_t i = (size_t)f * d.n_strips + s;
-            nbytes = (strip_bits[i] + 7) >> 3; // zero bits pad the strip to a byte, encoder.h:442-443
-            strip_bits[i] = 0;
-            strip_bytes[i] = nbytes;
-        }
-        uint32_t tot;
-        const uint32_t off = block_scan_exclusive(nbytes, ws, 256, tot);
-        if (s < d.n_strips) strip_off[(size_t)f * d.n_strips + s] = run_total + off;
-        run_total += tot;
-    }
-    if (threadIdx.x == 0) frame_size[f] = 44ull + run_total + 4ull;
-}
-
-struct SegGatherArgs {
-    SegGeom d;
-    const uint8_t *scratch;
-    const uint2 *seg;
-    const uint32_t *strip_bytes, *strip_off;
-    const unsigned long long *frame_size, *frame_off;
-    const Tables *tab;
-    uint8_t *out;
-    unsigned long long out_cap;
-    uint32_t *status;
-    int first_index;
-};
-
-// One wave per strip, kGatherStrips strips per workgroup ; a wave keeps its strip's segment table in
-// its own part of LDS (written and read by the same wave: no barrier).
-__global__ __launch_bounds__(kWave * kGatherStrips) void k_gather_segments(SegGatherArgs a) {
-    extern __shared__ uint32_t gl_all[]; // per wave: [segs + 1] bit prefix, [segs] bits, [segs] source word offset, [256] segment starts per output word
-    const SegGeom &d = a.d;
-    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int s = (int)blockIdx.x * kGatherStrips + wave, f = blockIdx.y, T = d.segs;
-    if (s >= d.n_strips) return;
-    const unsigned long long fo = a.frame_off[f], fs = a.frame_size[f];
-    if (fo + fs > a.out_cap) {
-        if (lane == 0 && s == 0) atomicOr(a.status, (uint32_t)M1V_STATUS_NOSPACE);
-        return;
-    }
-    const size_t idx = (size_t)f * d.n_strips + s;
-    uint32_t *gl = gl_all + wave * (3 * T + 1 + 4 * kWave);
-    uint32_t *pre = gl, *bits = gl + T + 1, *src = gl + 2 * T + 1, *starts = gl + 3 * T + 1;
-    // the strip's segment table: (bits, where) from memory, the bit offset of each segment by a wave scan over the tile rows
-    uint32_t carry = 0;
-    for (int t0 = 0; t0 < T; t0 += kWave) {
-        const int t = t0 + lane;
-        const uint2 sg = t < T ? a.seg[idx * T + t] : make_uint2(0u, 0u);
-        const uint32_t incl = wave_scan_inclusive(sg.x);
-        if (t < T) {
-            pre[t] = carry + incl - sg.x;
-            bits[t] = sg.x;
-            src[t] = sg.y;
-        }
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-    }
-    const uint32_t n = a.strip_bytes[idx];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the table is this wave's own: program order is enough
-    uint8_t *dst = a.out + fo + 44 + a.strip_off[idx];
-    const uint32_t nwords = (n + 3) >> 2;
-    // Four output words per lane and trip: their segment searches, then all source loads (unconditional, masked afterwards),
-    // then the stores — one memory latency per trip, and a strip (~1 KB) is one trip.
-    for (uint32_t base = 0; base < nwords; base += 4 * kWave) { // wave-uniform trips: every lane takes part in the counting
-        const uint32_t w0 = base + lane;
-        // k = the last segment that starts at or before the word's first bit = (segments that start at or before it) - 1.
-        // Counted, not searched (a binary search per word is five dependent LDS reads): every segment marks the first word
-        // that begins at or behind its start, a prefix sum over the trip's 256 words does the rest.
-#pragma unroll
-        for (int u = 0; u < 4; u++) starts[u * kWave + lane] = 0;
-        uint32_t before = 0; // segments that start before this trip's first word
-        for (int t0 = 0; t0 < T; t0 += kWave) {
-            const int t = t0 + lane;
-            const uint32_t wf = t < T ? (pre[t] + 31u) >> 5 : 0xffffffffu; // first word that begins at or behind the segment's start
-            before += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wf <= base));
-            if (wf > base && wf - base < 4u * kWave) atomicAdd(&starts[wf - base], 1u);
-        }
-        int k[4];
-        uint32_t run = before;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t incl = wave_scan_inclusive(starts[u * kWave + lane]);
-            k[u] = (int)(run + incl) - 1;
-            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-        }
-        unsigned long long win[4][2];
-        uint32_t sh[4][2], nb[4][2], at[4][2];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t lo_bit = 32u * (w0 + u * kWave);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int kq = min(k[u] + q, T - 1);
-                const uint32_t D = pre[kq], L = (k[u] + q < T) ? bits[kq] : 0u;
-                const uint32_t lo = max(lo_bit, D), hi = min(lo_bit + 32u, D + L);
-                const bool hit = hi > lo;
-                const uint32_t sb = hit ? lo - D : 0u;
-                nb[u][q] = hit ? hi - lo : 0u;
-                sh[u][q] = sb & 31u;
-                at[u][q] = hit ? lo - lo_bit : 0u;
-                const uint32_t *sp = reinterpret_cast<const uint32_t *>(a.scratch + (size_t)src[kq] * 4) + (sb >> 5);
-                win[u][q] = ((unsigned long long)__builtin_bswap32(sp[0]) << 32) | __builtin_bswap32(sp[1]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t w = w0 + u * kWave, lo_bit = 32u * w;
-            uint32_t val = 0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t b = nb[u][q] ? (uint32_t)((win[u][q] << sh[u][q]) >> (64u - nb[u][q])) : 0u;
-                val |= nb[u][q] ? b << (32u - at[u][q] - nb[u][q]) : 0u;
-            }
-            // (a third segment inside one word: only when a segment is shorter than 32 bits, i.e. a last tile row of one
-            //  macroblock row of all-minimal blocks)
-            for (int kk = k[u] + 2; w < nwords && kk < T && pre[kk] < lo_bit + 32u; kk++)
-                val |= strip_bits_from(a.scratch + (size_t)src[kk] * 4, pre[kk], bits[kk], lo_bit);
-            if (w < nwords) {
-                const uint32_t b0 = 4u * w;
-                uint8_t *o = dst + b0;
-                if (b0 + 4u <= n && ((uintptr_t)o & 3u) == 0) {
-                    *reinterpret_cast<uint32_t *>(o) = __builtin_bswap32(val);
-                } else {
-                    for (uint32_t q = 0; q < 4u && b0 + q < n; q++) o[q] = (uint8_t)(val >> (24u - 8u * q));
-                }
-            }
-        }
-    }
-    if (s == 0) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, lane);
-}
