@@ -13,30 +13,36 @@
 //   frame_bytes[frame]                     sum over the frame's strips of ceil(bits / 8): added by whoever completed a strip
 // so that NO value flows from workgroup to workgroup here: every workgroup derives its own place from those arrays.
 //
-// Mapping.  One workgroup (256 lanes) per (frame, GROUP of consecutive strips).  It
-//   1. sums frame_bytes[0 .. frame) (+ 48 per frame: PKT SEQ GOP PIC + trailer) = where its frame starts, and the byte counts of
-//      the frame's strips in front of its group = where its bytes start (two block reductions, all loads issued together);
-//   2. scans the bit counts of its group's segments — the strip padding rides on each strip's last segment — which gives every
-//      segment its destination bit in an LDS image of the group's output bytes; the image is laid out against the 16-byte
-//      grid of the OUTPUT address, so that
-//   3. SOURCE words scatter into it: 2^k lanes per segment read consecutive words (coalesced, several independent loads per
-//      lane in flight: one memory latency for the whole group) and OR them in at their destination phase (two ds_or_b32);
-//   4. the image leaves as aligned 16-byte stores; only the group's first and last partial units are written byte by byte
+// Mapping.  One workgroup (256 lanes = 4 waves) per (frame, GROUP of consecutive strips).
+//   1. Prologue, one job per wave, all at once: wave 0 sums frame_bytes[0 .. frame) (+ 48 per frame: PKT SEQ GOP PIC + trailer) =
+//      where the frame starts; wave 1 sums the bytes of the frame's strips in front of the group = where the group starts, and
+//      the group's own bytes; wave 2 scans the bit counts of the group's segments (a strip's zero padding rides on its last
+//      segment) = every segment's destination bit inside the group's bytes; all waves clear the LDS image.  One barrier.
+//   2. SOURCE words scatter into the image, which is laid out against the 16-byte grid of the OUTPUT address: 2^k lanes per
+//      segment, four consecutive source words per lane (one 16-byte load; the word in front of them comes from the neighbouring
+//      lane by DPP), one funnel shift (v_alignbit_b32) per destination word and one ds_or_b32 (neighbouring segments share
+//      their boundary word).  All loads of a trip are issued before the first is used.  One barrier.
+//   3. The image leaves as aligned 16-byte stores; only the group's first and last partial units are written byte by byte
 //      (their other bytes belong to the neighbouring groups, the frame header or the trailer).
-// A group whose bytes outgrow the image takes several passes over its segments (any picture, any quality: correct; the host
-// sizes groups so that noise at the encoder's quality needs one).
+// A group whose bytes outgrow the image takes several passes over its segments, a group of more than 256 segments several
+// chunks (any picture, any quality: correct; the host sizes groups so that noise at the encoder's quality needs one of each).
+//
+// What bounds it (tools/asm_stamps.py: a timeline of every workgroup; tools/pmc_asm.sh): INSTRUCTION ISSUE.  The first forms of
+// this kernel spent 1,300-2,500 instructions per wave — every wave repeating the reductions and the scan, 64-bit vector
+// addressing, one lane per source word — and ran 37-46 us for 300 x 1080p at any occupancy (23 M wave instructions over 1,024
+// SIMDs).  Hence the one-job-per-wave prologue, scalar bases with 32-bit offsets, and four words per lane.
 constexpr unsigned long long kCtrBitsMask = (1ull << 40) - 1; // strip_ctr: bits of the strip; above: tile rows that have arrived
 constexpr int kCtrCountShift = 40;
 constexpr int kAsmThreads = 256;
 constexpr int kAsmMaxGroup = 16;
-// LDS words behind the image: 12 x u64 reduction slots, 2 x 16 + 4 scan words, placement of <= 256 segments, per-strip bytes and padding
-constexpr int kAsmRed = 0, kAsmScan = 24, kAsmDst = 60, kAsmBits = kAsmDst + kAsmThreads, kAsmSrc = kAsmBits + kAsmThreads,
-              kAsmStripBytes = kAsmSrc + kAsmThreads, kAsmStripPad = kAsmStripBytes + kAsmMaxGroup, kAsmFixedWords = kAsmStripPad + kAsmMaxGroup;
+// LDS words behind the image: [0..1] frame offset (u64), [2] bytes in front of the group, [3] bytes of the frame's strips,
+// [4] bytes of the group; from word 16: placement of <= 256 segments (16 bytes each)
+constexpr int kAsmPlace = 16, kAsmFixedWords = kAsmPlace + 4 * kAsmThreads;
 
 struct AssembleArgs {
     int n_frames, n_strips, segs; // segs = segments per strip
     int group;                    // strips per workgroup (<= kAsmMaxGroup)
-    int lanes_log2;               // 2^k lanes share a segment
+    int lanes_log2;               // 2^k lanes (of four words each) share a segment, k <= 4
     int img_words;                // LDS image capacity in words (multiple of 4)
     DivMagic div_segs;            // division of a segment index by segs
     const uint8_t *scratch;
@@ -53,6 +59,7 @@ struct AssembleArgs {
     unsigned long long *out_sizes, *out_total; // may be null
     uint32_t *out_status;
     int first_index;
+    unsigned long long *stamps; // diagnostic builds only (-DM1V_ASM_STAMPS, tools/asm_stamps.py)
 };
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -60,61 +67,144 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
     return v;
 }
-
-// OR the top `nb` bits of `word` (MSB first) into the image at bit `rel` (relative to the pass; may lie outside it)
-__device__ __forceinline__ void asm_place(uint32_t *img, int capw, int rel, uint32_t word, uint32_t nb) {
-    const uint32_t val = nb >= 32u ? word : (word & ~(0xffffffffu >> nb));
-    const int wi = rel >> 5; // arithmetic: floor for the words that start in front of the pass
-    const uint32_t sh = (uint32_t)rel & 31u;
-    const uint32_t hi = val >> sh, lo = sh ? val << (32u - sh) : 0u;
-    if (hi && (unsigned)wi < (unsigned)capw) atomicOr(&img[wi], hi);
-    if (lo && (unsigned)(wi + 1) < (unsigned)capw) atomicOr(&img[wi + 1], lo);
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(v), kWave - 1); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// the top min(max(nb, 0), 32) bits set
+__device__ __forceinline__ uint32_t asm_top_bits(int nb) { return (uint32_t)(0xffffffff00000000ull >> (uint32_t)min(max(nb, 0), 32)); }
+
+struct __attribute__((aligned(4))) AsmWords4 {
+    uint32_t w[4];
+};
+
+#ifndef M1V_ASM_U
+#define M1V_ASM_U 5 // segments per lane and trip: 8 lanes per segment x 5 trips of 32 = 160 segments in flight (1080p: 8 strips x 17, 4K: 4 x 34)
+#endif
+
+// Diagnostic build only: cycles thread 0 of every workgroup spends in each phase, added to AssembleArgs::stamps at the end.
+#ifdef M1V_ASM_STAMPS
+#define ASTAMP(ph)                                                                                 \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        astamp_[ph] = __builtin_amdgcn_s_memrealtime();                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)");                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define ASTAMP_INIT()                                                                              \
+    unsigned long long astamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                      \
+    const unsigned long long astamp_t_ = __builtin_amdgcn_s_memrealtime();                         \
+    asm volatile("s_waitcnt lgkmcnt(0)")
+#define ASTAMP_FLUSH()                                                                             \
+    do {                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        ASTAMP(6);                                                                                 \
+        if (threadIdx.x == 0) {                                                                    \
+            unsigned long long *tl_ = a.stamps + 32 + 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x); \
+            tl_[0] = astamp_t_;                                                                    \
+            for (int ph_ = 0; ph_ < 7; ph_++) tl_[1 + ph_] = astamp_[ph_];                         \
+        }                                                                                          \
+    } while (0)
+#else
+#define ASTAMP(ph) do { } while (0)
+#define ASTAMP_INIT() do { } while (0)
+#define ASTAMP_FLUSH() do { } while (0)
+#endif
+
+// WIDE: the scratch is 4 GiB or more (byte offsets of source words need 64 bits)
+template <bool WIDE>
 __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t asm_lds[];
+    ASTAMP_INIT();
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = blockIdx.y, s0 = (int)blockIdx.x * a.group, ns = min(a.group, a.n_strips - s0), T = a.segs;
     uint32_t *img = asm_lds, *fixed = asm_lds + a.img_words;
-    unsigned long long *red = reinterpret_cast<unsigned long long *>(fixed + kAsmRed);
-    uint32_t *ws = fixed + kAsmScan, *sd = fixed + kAsmDst, *sb = fixed + kAsmBits, *sw = fixed + kAsmSrc, *sbytes = fixed + kAsmStripBytes,
-             *spad = fixed + kAsmStripPad;
-
-    // ---- 1. where the frame starts, where the group starts inside it ----
+    uint4 *place = reinterpret_cast<uint4 *>(fixed + kAsmPlace); // per segment: destination bit (from the group's first byte), bits, source word, -
     const unsigned long long *ctr_f = a.strip_ctr + (size_t)f * a.n_strips;
-    unsigned long long in_front = 0, before = 0, payload = 0;
-    for (int i = tid; i < f; i += kAsmThreads) in_front += 48ull + a.frame_bytes[i];
-    for (int s = tid; s < a.n_strips; s += kAsmThreads) {
-        const unsigned long long b = ((ctr_f[s] & kCtrBitsMask) + 7ull) >> 3; // zero bits pad a strip to a byte, encoder.h:442-443
-        payload += b;
-        before += s < s0 ? b : 0ull;
-    }
-    if (tid < ns) {
-        const unsigned long long bits = ctr_f[s0 + tid] & kCtrBitsMask, bytes = (bits + 7ull) >> 3;
-        sbytes[tid] = (uint32_t)bytes;
-        spad[tid] = (uint32_t)(8ull * bytes - bits);
-    }
-    in_front = wave_sum_u64(in_front);
-    before = wave_sum_u64(before);
-    payload = wave_sum_u64(payload);
-    if (lane == 0) {
-        red[wave * 3 + 0] = in_front;
-        red[wave * 3 + 1] = before;
-        red[wave * 3 + 2] = payload;
-    }
-    __syncthreads();
-    const unsigned long long fo = red[0] + red[3] + red[6] + red[9], B0 = red[1] + red[4] + red[7] + red[10],
-                             fs = 48ull + red[2] + red[5] + red[8] + red[11];
-    const bool fits = fo + fs <= a.out_cap;
+    const int nseg = ns * T;
+    const uint2 *seg_g = a.seg + ((size_t)f * a.n_strips + s0) * T;
+    const uint32_t cap_bytes = (uint32_t)a.img_words * 4u;
 
-    // ---- housekeeping: sizes, total, status; the next batch's counters ----
-    if (f < a.next_frames) {
-        if (tid < ns) a.next_strip_ctr[(size_t)f * a.n_strips + s0 + tid] = 0ull;
-        if (blockIdx.x == 0 && tid == 0) a.next_frame_bytes[f] = 0ull;
+    // Destination bits of segments [c0, c0 + 256) -> place[]: one wave, four blocks of 64, loads first.  A strip's padding (zero
+    // bits up to a byte, encoder.h:442-443) rides on its last segment, so the scan runs through strip boundaries.
+    auto scan_chunk = [&](int c0, uint32_t &carry) {
+        uint2 sg[4];
+        unsigned long long ctr[4];
+        bool last[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = c0 + 64 * k + lane, j = (int)udiv((uint32_t)min(q, nseg - 1), a.div_segs);
+            last[k] = q - j * T == T - 1;
+            sg[k] = seg_g[min(q, nseg - 1)];
+            ctr[k] = ctr_f[s0 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = c0 + 64 * k + lane;
+            const uint32_t bits = q < nseg ? sg[k].x : 0u;
+            const uint32_t v = bits + (q < nseg && last[k] ? (0u - (uint32_t)ctr[k]) & 7u : 0u);
+            const uint32_t incl = wave_scan_inclusive(v);
+            place[64 * k + lane] = make_uint4(carry + incl - v, bits, sg[k].y, 0u);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        }
+    };
+    auto clear_image = [&](uint32_t bytes) {
+        uint4 *img4 = reinterpret_cast<uint4 *>(img);
+        for (uint32_t k = tid; k < ((bytes + 15u) >> 4); k += kAsmThreads) img4[k] = make_uint4(0u, 0u, 0u, 0u);
+    };
+
+    // ---- 1. prologue: one job per wave (every load unconditional: clamped index, masked afterwards) ----
+    uint32_t carry = 0; // wave 2: destination bit of the next chunk's first segment
+    if (wave == 0) {
+        unsigned long long acc = 0; // where the frame starts: 48 bytes of headers and trailer + its strips, for every frame in front
+        for (int i0 = 0; i0 < f; i0 += 4 * kWave) {
+            unsigned long long v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = a.frame_bytes[min(i0 + kWave * k + lane, a.n_frames - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += i0 + kWave * k + lane < f ? 48ull + v[k] : 0ull;
+        }
+        // (a lane's sum stays far below 2^56: two 32-bit reductions)
+        const uint32_t lo = wave_sum_u32((uint32_t)acc & 0xffffffu), hi = wave_sum_u32((uint32_t)(acc >> 24));
+        if (lane == 0) *reinterpret_cast<unsigned long long *>(fixed) = ((unsigned long long)hi << 24) + lo;
+    } else if (wave == 1) {
+        uint32_t before = 0, payload = 0; // bytes of the frame's strips: below 4 GiB (m1v_create bounds the frame)
+        for (int t0 = 0; t0 < a.n_strips; t0 += 2 * kWave) {
+            const unsigned long long c0 = ctr_f[min(t0 + lane, a.n_strips - 1)], c1 = ctr_f[min(t0 + kWave + lane, a.n_strips - 1)];
+            const uint32_t b0 = t0 + lane < a.n_strips ? (uint32_t)(((c0 & kCtrBitsMask) + 7ull) >> 3) : 0u;
+            const uint32_t b1 = t0 + kWave + lane < a.n_strips ? (uint32_t)(((c1 & kCtrBitsMask) + 7ull) >> 3) : 0u;
+            payload += b0 + b1;
+            before += (t0 + lane < s0 ? b0 : 0u) + (t0 + kWave + lane < s0 ? b1 : 0u);
+        }
+        const unsigned long long own = ctr_f[s0 + min(lane, ns - 1)];
+        const uint32_t own_bytes = lane < ns ? (uint32_t)(((own & kCtrBitsMask) + 7ull) >> 3) : 0u;
+        const uint32_t group_incl = row_scan_inclusive(own_bytes); // lanes 0..15 hold the group (<= kAsmMaxGroup strips)
+        before = wave_sum_u32(before);
+        payload = wave_sum_u32(payload);
+        if (lane == 0) {
+            fixed[2] = before;
+            fixed[3] = payload;
+        }
+        if (lane == 15) fixed[4] = group_incl;
+        if (f < a.next_frames && lane < ns) a.next_strip_ctr[(size_t)f * a.n_strips + s0 + lane] = 0ull;
+    } else if (wave == 2) {
+        scan_chunk(0, carry);
     }
-    if (blockIdx.x == 0) {
-        if (fits) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, tid);
-        if (tid == 0) {
+    clear_image(cap_bytes);
+    __syncthreads();
+    const unsigned long long fo = uniform_u64(*reinterpret_cast<const unsigned long long *>(fixed));
+    const uint32_t B0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)fixed[2]);
+    const unsigned long long fs = 48ull + (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)fixed[3]);
+    const uint32_t group_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)fixed[4]);
+    const bool fits = fo + fs <= a.out_cap;
+    ASTAMP(0);
+
+    // ---- housekeeping (wave 3 of the frame's first group): header, trailer, sizes, total, status; the next batch's counters ----
+    if (blockIdx.x == 0 && wave == 3) {
+        if (fits) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, lane);
+        if (lane == 0) {
+            if (f < a.next_frames) a.next_frame_bytes[f] = 0ull;
             if (a.out_sizes) a.out_sizes[f] = fs;
             if (f == a.n_frames - 1) {
                 // frames are laid out one behind the other: the batch fits iff its last frame does
@@ -126,95 +216,112 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         }
     }
     if (!fits) return;
+    ASTAMP(1);
 
-    uint32_t group_bytes = 0;
-    for (int j = 0; j < ns; j++) group_bytes += sbytes[j];
     const uintptr_t A0 = reinterpret_cast<uintptr_t>(a.out) + fo + 44ull + B0, a_lo = A0 & ~(uintptr_t)15;
     const uint32_t lead = (uint32_t)(A0 - a_lo), img_end = lead + group_bytes; // the group's bytes are image bytes [lead, img_end)
-    const uint32_t cap_bytes = (uint32_t)a.img_words * 4u;
-    const int nseg = ns * T;
-    const uint2 *seg_g = a.seg + ((size_t)f * a.n_strips + s0) * T;
-    const uint32_t *src32 = reinterpret_cast<const uint32_t *>(a.scratch);
-    const int lg = a.lanes_log2, L = 1 << lg, sub = tid & (L - 1), slot = tid >> lg, per_trip = kAsmThreads >> lg;
-    constexpr int U = 4; // independent source loads per lane in flight
+    const int lg = a.lanes_log2, L = 1 << lg, sub = tid & (L - 1), slot = tid >> lg, per_trip = kAsmThreads >> lg, w0 = 4 * sub;
+    constexpr int U = M1V_ASM_U;
+    // four source words from word x of the scratch: a scalar base + a 32-bit byte offset unless the scratch is 4 GiB or more
+    auto src_words = [&](uint32_t x) -> AsmWords4 {
+        if (WIDE) return *reinterpret_cast<const AsmWords4 *>(a.scratch + ((size_t)x << 2));
+        return *reinterpret_cast<const AsmWords4 *>(a.scratch + (x << 2));
+    };
+    // Destination words w .. w + 3 of a segment of `b` bits from its source words w - 1 (`prv`), w .. w + 3: each is the funnel
+    // shift of two neighbours by the segment's phase; words past the segment's end are masked away, so that word `words of the
+    // segment` comes out as the tail the last source word leaves.
+    auto scatter4 = [&](const AsmWords4 &cur, uint32_t prv, int b, int w, uint32_t sh, int k0, int capw) {
+        uint32_t p = w > 0 ? __builtin_bswap32(prv) & asm_top_bits(b - 32 * w + 32) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t c = __builtin_bswap32(cur.w[k]) & asm_top_bits(b - 32 * (w + k));
+            const uint32_t o = __builtin_amdgcn_alignbit(p, c, sh);
+            if (o != 0u && (unsigned)(k0 + k) < (unsigned)capw) atomicOr(&img[k0 + k], o);
+            p = c;
+        }
+    };
 
-    int parity = 0;
     for (uint32_t pass0 = 0; pass0 < img_end; pass0 += cap_bytes) { // image bytes [pass0, pass0 + cap_bytes) of this pass
         const uint32_t pass_bytes = min(cap_bytes, img_end - pass0);
-        {
-            uint4 *img4 = reinterpret_cast<uint4 *>(img);
-            for (uint32_t k = tid; k < ((pass_bytes + 15u) >> 4); k += kAsmThreads) img4[k] = make_uint4(0u, 0u, 0u, 0u);
+        const int word0 = (int)(pass0 >> 2), capw = (int)((pass_bytes + 3u) >> 2); // the pass's words of the image
+        if (pass0 != 0) {
+            clear_image(pass_bytes);
+            carry = 0;
         }
-        const uint32_t bit0 = pass0 * 8u, bit1 = bit0 + pass_bytes * 8u;
-        uint32_t carry = lead * 8u; // destination bit (image space) of the chunk's first segment
         for (int c0 = 0; c0 < nseg; c0 += kAsmThreads) {
-            // ---- 2. destination bit of every segment: a scan of the bit counts, the strip's padding on its last segment ----
-            const int q = c0 + tid;
-            uint2 sg = make_uint2(0u, 0u);
-            uint32_t v = 0;
-            if (q < nseg) {
-                sg = seg_g[q];
-                const int j = (int)udiv((uint32_t)q, a.div_segs), t = q - j * T;
-                v = sg.x + (t == T - 1 ? spad[j] : 0u);
+            if (pass0 != 0 || c0 != 0) { // (the first chunk of the first pass was placed in the prologue)
+                if (wave == 2) scan_chunk(c0, carry);
+                __syncthreads();
             }
-            uint32_t tot;
-            const uint32_t excl = block_scan_exclusive_1b(v, ws, parity, kAsmThreads, tot);
-            parity ^= 1;
-            sd[tid] = carry + excl;
-            sb[tid] = sg.x;
-            sw[tid] = sg.y;
-            carry += tot;
-            const int any_long = __syncthreads_or(sg.x > 32u * (uint32_t)L); // (also: the image is cleared, the placement is in LDS)
             const int cnt = min(kAsmThreads, nseg - c0);
+            ASTAMP(2);
 
-            // ---- 3. source words into the image: word `sub` of U segments per trip, all loads first ----
+            // ---- 2. four destination words of U segments per lane and trip: all loads first ----
             for (int e0 = 0; e0 < cnt; e0 += per_trip * U) {
-                uint32_t word[U], nb[U];
-                int rel[U];
+                AsmWords4 cur[U];
+                uint32_t sh[U];
+                int bits[U], k0[U];
+                bool more = false;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int e = e0 + u * per_trip + slot;
-                    const bool ok = e < cnt;
-                    const int ee = ok ? e : 0;
-                    const uint32_t d = sd[ee] + 32u * (uint32_t)sub, b = ok ? sb[ee] : 0u;
-                    const bool have = 32u * (uint32_t)sub < b && d + 32u > bit0 && d < bit1;
-                    nb[u] = have ? min(32u, b - 32u * (uint32_t)sub) : 0u;
-                    rel[u] = (int)(d - bit0);
-                    word[u] = have ? src32[(size_t)sw[ee] + (uint32_t)sub] : 0u;
+                    const uint4 pl = place[min(e, cnt - 1)];
+                    const int b = e < cnt ? (int)pl.y : 0;
+                    const uint32_t d = pl.x + 8u * lead;
+                    bits[u] = b;
+                    sh[u] = d & 31u;
+                    k0[u] = (int)(d >> 5) - word0 + w0;
+                    more |= b + 32 > 128 * L;
+                    // lanes behind the segment's end read its first words (an empty segment's: the first words of the scratch)
+                    cur[u] = src_words(pl.z + (32 * w0 < b ? (uint32_t)w0 : 0u));
                 }
+#ifdef M1V_ASM_SB
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-                for (int u = 0; u < U; u++)
-                    if (nb[u]) asm_place(img, a.img_words, rel[u], __builtin_bswap32(word[u]), nb[u]);
-            }
-            if (any_long) { // segments of more than 32 * L bits: the rest of their words
-                for (int e = slot; e < cnt; e += per_trip) {
-                    const uint32_t b = sb[e], d0 = sd[e];
-                    const size_t from = sw[e];
-                    for (uint32_t w = (uint32_t)(sub + L); 32u * w < b; w += (uint32_t)L) {
-                        const uint32_t d = d0 + 32u * w;
-                        if (d + 32u > bit0 && d < bit1)
-                            asm_place(img, a.img_words, (int)(d - bit0), __builtin_bswap32(src32[from + w]), min(32u, b - 32u * w));
+                for (int u = 0; u < U; u++) {
+                    // the word in front of the lane's four: the neighbouring lane's last (row_shr:1; lane 0 of a segment has none)
+                    const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[u].w[3], 0x111, 0xf, 0xf, true);
+                    scatter4(cur[u], prv, bits[u], w0, sh[u], k0[u], capw);
+                }
+                // segments of more than 128 * L - 32 bits (rare at the quality the host sized L for): the rest of their words
+                if (__builtin_amdgcn_ballot_w64(more)) {
+#pragma unroll 1
+                    for (int u = 0; u < U; u++) {
+                        const int e = e0 + u * per_trip + slot;
+                        if (bits[u] + 32 <= 128 * L) continue;
+                        const uint32_t from = place[e].z;
+                        for (int w = w0 + 4 * L; 32 * w < bits[u] + 32; w += 4 * L) {
+                            const AsmWords4 c = src_words(from + (uint32_t)(32 * w < bits[u] ? w : 0));
+                            const uint32_t prv = src_words(from + (uint32_t)(w - 1)).w[0];
+                            scatter4(c, prv, bits[u], w, sh[u], k0[u] - w0 + w, capw);
+                        }
                     }
                 }
             }
+            ASTAMP(3);
             __syncthreads(); // the chunk's placement has been used; behind the last chunk: the image is complete
+            ASTAMP(4);
         }
 
-        // ---- 4. the image leaves: aligned 16-byte units, the group's two partial units byte by byte ----
+        // ---- 3. the image leaves: aligned 16-byte units, the group's two partial units byte by byte ----
         const uint4 *img4 = reinterpret_cast<const uint4 *>(img);
+        uint8_t *const out_lo = reinterpret_cast<uint8_t *>(a_lo) + pass0; // uniform
         for (uint32_t k = tid; 16u * k < pass_bytes; k += kAsmThreads) {
             const uint32_t ib = pass0 + 16u * k; // image byte of the unit
             const uint4 v = img4[k];
-            uint8_t *o = reinterpret_cast<uint8_t *>(a_lo + ib);
             if (ib >= lead && ib + 16u <= img_end) {
-                *reinterpret_cast<uint4 *>(o) = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+                *reinterpret_cast<uint4 *>(out_lo + 16u * k) =
+                    make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w));
             } else {
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (uint32_t b = 0; b < 16u; b++)
-                    if (ib + b >= lead && ib + b < img_end) o[b] = (uint8_t)(w4[b >> 2] >> (24u - 8u * (b & 3u)));
+                    if (ib + b >= lead && ib + b < img_end) out_lo[16u * k + b] = (uint8_t)(w4[b >> 2] >> (24u - 8u * (b & 3u)));
             }
         }
+        ASTAMP(5);
         if (pass0 + cap_bytes < img_end) __syncthreads(); // the next pass clears the image
     }
+    ASTAMP_FLUSH();
 }

@@ -1635,7 +1635,7 @@ int m1v_warm_up(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr)); // creates the context
     hipFuncAttributes attr;    // loads this library's code object for the device
-    HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_assemble)));
+    HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_assemble<false>)));
     return M1V_OK;
 }
 
@@ -1757,7 +1757,7 @@ static int configure_path(m1v_encoder *e) {
     }
     // k_assemble (m1v_assemble.h): strips per workgroup so that a group's bytes fit its 16-KiB LDS image in one pass on noise at
     // this quality (19 bits per block at quality 12; anything larger takes more passes), a power of two (the eight
-    // strips of a tile column share their scratch lines); lanes per segment ~ the words a segment holds.
+    // strips of a tile column share their scratch lines); lanes per segment (four words each) ~ the words a segment holds.
     int asm_group, asm_lanes_log2;
     {
         const int qscale = e->qf <= 25 ? 1 : (e->qf <= 50 ? 2 : (e->qf <= 76 ? 4 : 8));
@@ -1767,8 +1767,8 @@ static int configure_path(m1v_encoder *e) {
         while (asm_group < kAsmMaxGroup && (size_t)(2 * asm_group) * strip_est * 5 / 4 <= 16384 && 2 * asm_group <= g.n_strips) asm_group *= 2;
         const size_t seg_blocks = plan.tiles ? (size_t)kTileSegBlocks : (e->dense ? (size_t)plan.dense_T : (size_t)bps);
         const size_t seg_words = seg_blocks * bpb / 32;
-        asm_lanes_log2 = 2;
-        while (asm_lanes_log2 < 6 && ((size_t)1 << asm_lanes_log2) * 4 < seg_words * 3) asm_lanes_log2++;
+        asm_lanes_log2 = 1; // four words per lane: enough lanes for 1.6 x the expected words, at most one DPP row
+        while (asm_lanes_log2 < 4 && ((size_t)4 << asm_lanes_log2) * 5 < seg_words * 8) asm_lanes_log2++;
     }
     const int sets = e->pipelined ? 2 : 1;
     segb = (size_t)e->max_frames * g.n_strips * segs * sizeof(uint2);
@@ -1939,9 +1939,9 @@ int m1v_create(m1v_encoder **out, int device, int width, int height, int channel
     hipError_t err = hipMalloc(&e->d_tab, sizeof(Tables));
     if (err == hipSuccess) err = hipMemcpy(e->d_tab, t, sizeof(Tables), hipMemcpyHostToDevice);
     delete t;
-#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS)
-    if (err == hipSuccess) err = hipMalloc(&e->d_stamps, 32 * 8);
-    if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, 32 * 8);
+#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS) || defined(M1V_ASM_STAMPS)
+    if (err == hipSuccess) err = hipMalloc(&e->d_stamps, (32 + 8 * 65536) * 8); // [32] phase sums, then a timeline of 8 stamps per workgroup
+    if (err == hipSuccess) err = hipMemset(e->d_stamps, 0, (32 + 8 * 65536) * 8);
 #endif
     if (err == hipSuccess) err = configure_path(e) == M1V_OK ? hipSuccess : hipErrorOutOfMemory;
     const void *kernels[] = {(const void *)&k_encode_dense<1, true>, (const void *)&k_encode_dense<1, false>,
@@ -2093,13 +2093,20 @@ int m1v_path_in_use(const m1v_encoder *e) { return e ? (e->tiles ? 1 : 0) : -1; 
 
 void m1v_debug_fail_alloc(int nth) { g_fail_alloc_in = nth > 0 ? nth : 0; }
 
-#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS)
+#if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS) || defined(M1V_ASM_STAMPS)
 // diagnostic builds only: read and clear the per-phase cycle sums
 int m1v_debug_read_stamps(m1v_encoder *e, unsigned long long out[32]) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, e->d_stamps, 32 * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(e->d_stamps, 0, 32 * 8));
+    return M1V_OK;
+}
+// diagnostic builds only: the per-workgroup timeline of the last k_assemble launch (8 stamps each)
+int m1v_debug_read_timeline(m1v_encoder *e, unsigned long long *out, int workgroups) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->d_stamps + 32, (size_t)(workgroups > 65536 ? 65536 : workgroups) * 64, hipMemcpyDeviceToHost));
     return M1V_OK;
 }
 #endif
@@ -2351,8 +2358,13 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         ga.out_total = (unsigned long long *)d_total;
         ga.out_status = d_status ? d_status : cur.words + 1;
         ga.first_index = first_frame_index;
-        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((g.n_strips + e->asm_group - 1) / e->asm_group), (unsigned)n_frames), dim3(kAsmThreads),
-                           (size_t)(e->asm_img_words + kAsmFixedWords) * sizeof(uint32_t), gs, ga);
+        ga.stamps = e->d_stamps;
+        const dim3 grid((unsigned)((g.n_strips + e->asm_group - 1) / e->asm_group), (unsigned)n_frames);
+        const size_t lds = (size_t)(e->asm_img_words + kAsmFixedWords) * sizeof(uint32_t);
+        if (e->scratch_bytes >= (1ull << 32))
+            hipLaunchKernelGGL(k_assemble<true>, grid, dim3(kAsmThreads), lds, gs, ga);
+        else
+            hipLaunchKernelGGL(k_assemble<false>, grid, dim3(kAsmThreads), lds, gs, ga);
         HIP_TRY(hipGetLastError());
     }
     if (e->pipelined) {

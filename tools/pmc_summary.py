@@ -17,6 +17,8 @@ def short(k):
         return "k_encode_tiles"
     if "k_gather" in k:
         return "k_gather"
+    if "k_assemble" in k:
+        return "k_assemble"
     return None
 
 
