@@ -132,8 +132,10 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         uint2 sg[4];
         unsigned long long ctr[4];
         bool last[4];
+        const int blocks = min(4, (nseg - c0 + kWave - 1) / kWave); // uniform
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            if (k >= blocks) break;
             const int q = c0 + 64 * k + lane, j = (int)udiv((uint32_t)min(q, nseg - 1), a.div_segs);
             last[k] = q - j * T == T - 1;
             sg[k] = seg_g[min(q, nseg - 1)];
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            if (k >= blocks) break;
             const int q = c0 + 64 * k + lane;
             const uint32_t bits = q < nseg ? sg[k].x : 0u;
             const uint32_t v = bits + (q < nseg && last[k] ? (0u - (uint32_t)ctr[k]) & 7u : 0u);
@@ -158,12 +161,12 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     uint32_t carry = 0; // wave 2: destination bit of the next chunk's first segment
     if (wave == 0) {
         unsigned long long acc = 0; // where the frame starts: 48 bytes of headers and trailer + its strips, for every frame in front
-        for (int i0 = 0; i0 < f; i0 += 4 * kWave) {
-            unsigned long long v[4];
+        for (int i0 = 0; i0 < f; i0 += 8 * kWave) { // eight loads in flight per lane: one trip up to 512 frames
+            unsigned long long v[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = a.frame_bytes[min(i0 + kWave * k + lane, a.n_frames - 1)];
+            for (int k = 0; k < 8; k++) v[k] = a.frame_bytes[min(i0 + kWave * k + lane, a.n_frames - 1)];
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc += i0 + kWave * k + lane < f ? 48ull + v[k] : 0ull;
+            for (int k = 0; k < 8; k++) acc += i0 + kWave * k + lane < f ? 48ull + v[k] : 0ull;
         }
         // (a lane's sum stays far below 2^56: two 32-bit reductions)
         const uint32_t lo = wave_sum_u32((uint32_t)acc & 0xffffffu), hi = wave_sum_u32((uint32_t)(acc >> 24));
@@ -227,19 +230,27 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         if (WIDE) return *reinterpret_cast<const AsmWords4 *>(a.scratch + ((size_t)x << 2));
         return *reinterpret_cast<const AsmWords4 *>(a.scratch + (x << 2));
     };
-    // Destination words w .. w + 3 of a segment of `b` bits from its source words w - 1 (`prv`), w .. w + 3: each is the funnel
-    // shift of two neighbours by the segment's phase; words past the segment's end are masked away, so that word `words of the
-    // segment` comes out as the tail the last source word leaves.
-    auto scatter4 = [&](const AsmWords4 &cur, uint32_t prv, int b, int w, uint32_t sh, int k0, int capw) {
-        uint32_t p = w > 0 ? __builtin_bswap32(prv) & asm_top_bits(b - 32 * w + 32) : 0u;
+    // Destination words w .. w + 3 of a segment of `nw` source words from its words w - 1 (`p`: swapped, zero if there is none),
+    // w .. w + 3: each is the funnel shift of two neighbours by the segment's phase.  Words past the segment's end count as
+    // zero, so that destination word `nw` comes out as the tail the last source word leaves; the padding bits of a segment's
+    // last word ARE zero (every encode kernel builds its segments from word boundaries of a cleared image).  CHECK: the pass
+    // does not hold every word the lanes may touch.  Returns the lane's last source word (swapped, masked).
+    auto scatter4 = [&](auto check, const AsmWords4 &cur, uint32_t p, int nw, int w, uint32_t sh, int k0, int capw) -> uint32_t {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t c = __builtin_bswap32(cur.w[k]) & asm_top_bits(b - 32 * (w + k));
+            const uint32_t c = w + k < nw ? __builtin_bswap32(cur.w[k]) : 0u;
             const uint32_t o = __builtin_amdgcn_alignbit(p, c, sh);
-            if (o != 0u && (unsigned)(k0 + k) < (unsigned)capw) atomicOr(&img[k0 + k], o);
+            if (!decltype(check)::value)
+                atomicOr(&img[k0 + k], o);
+            else if (o != 0u && (unsigned)(k0 + k) < (unsigned)capw)
+                atomicOr(&img[k0 + k], o);
             p = c;
         }
+        return p;
     };
+    // a lane reaches at most 4 * L + 3 words behind the start of its segment's destination: one pass without range checks
+    // if that still lies inside the image
+    const bool unchecked = img_end + 4u * (4u * (uint32_t)L + 4u) <= cap_bytes;
 
     for (uint32_t pass0 = 0; pass0 < img_end; pass0 += cap_bytes) { // image bytes [pass0, pass0 + cap_bytes) of this pass
         const uint32_t pass_bytes = min(cap_bytes, img_end - pass0);
@@ -260,41 +271,50 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
             for (int e0 = 0; e0 < cnt; e0 += per_trip * U) {
                 AsmWords4 cur[U];
                 uint32_t sh[U];
-                int bits[U], k0[U];
+                int nw[U], k0[U]; // source words of the segment; image word of the lane's first destination word
                 bool more = false;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int e = e0 + u * per_trip + slot;
                     const uint4 pl = place[min(e, cnt - 1)];
-                    const int b = e < cnt ? (int)pl.y : 0;
                     const uint32_t d = pl.x + 8u * lead;
-                    bits[u] = b;
+                    nw[u] = e < cnt ? (int)((pl.y + 31u) >> 5) : 0;
                     sh[u] = d & 31u;
                     k0[u] = (int)(d >> 5) - word0 + w0;
-                    more |= b + 32 > 128 * L;
+                    more |= nw[u] >= 4 * L;
                     // lanes behind the segment's end read its first words (an empty segment's: the first words of the scratch)
-                    cur[u] = src_words(pl.z + (32 * w0 < b ? (uint32_t)w0 : 0u));
+                    cur[u] = src_words(pl.z + (w0 < nw[u] ? (uint32_t)w0 : 0u));
                 }
 #ifdef M1V_ASM_SB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+                if (unchecked) {
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    // the word in front of the lane's four: the neighbouring lane's last (row_shr:1; lane 0 of a segment has none)
-                    const uint32_t prv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur[u].w[3], 0x111, 0xf, 0xf, true);
-                    scatter4(cur[u], prv, bits[u], w0, sh[u], k0[u], capw);
+                    for (int u = 0; u < U; u++) {
+                        // the word in front of the lane's four: the neighbouring lane's last, swapped and masked there (row_shr:1)
+                        const uint32_t last = w0 + 3 < nw[u] ? __builtin_bswap32(cur[u].w[3]) : 0u;
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x111, 0xf, 0xf, true);
+                        scatter4(std::false_type(), cur[u], sub ? p : 0u, nw[u], w0, sh[u], k0[u], capw);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t last = w0 + 3 < nw[u] ? __builtin_bswap32(cur[u].w[3]) : 0u;
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x111, 0xf, 0xf, true);
+                        scatter4(std::true_type(), cur[u], sub ? p : 0u, nw[u], w0, sh[u], k0[u], capw);
+                    }
                 }
-                // segments of more than 128 * L - 32 bits (rare at the quality the host sized L for): the rest of their words
+                // segments of more than 4 * L - 1 words (rare at the quality the host sized L for): the rest of their words
                 if (__builtin_amdgcn_ballot_w64(more)) {
 #pragma unroll 1
                     for (int u = 0; u < U; u++) {
                         const int e = e0 + u * per_trip + slot;
-                        if (bits[u] + 32 <= 128 * L) continue;
+                        if (nw[u] < 4 * L) continue;
                         const uint32_t from = place[e].z;
-                        for (int w = w0 + 4 * L; 32 * w < bits[u] + 32; w += 4 * L) {
-                            const AsmWords4 c = src_words(from + (uint32_t)(32 * w < bits[u] ? w : 0));
-                            const uint32_t prv = src_words(from + (uint32_t)(w - 1)).w[0];
-                            scatter4(c, prv, bits[u], w, sh[u], k0[u] - w0 + w, capw);
+                        for (int w = w0 + 4 * L; w <= nw[u]; w += 4 * L) {
+                            const AsmWords4 c = src_words(from + (uint32_t)(w < nw[u] ? w : 0));
+                            const uint32_t p = __builtin_bswap32(src_words(from + (uint32_t)(w - 1)).w[0]);
+                            scatter4(std::true_type(), c, p, nw[u], w, sh[u], k0[u] - w0 + w, capw);
                         }
                     }
                 }

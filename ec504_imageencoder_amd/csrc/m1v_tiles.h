@@ -384,6 +384,11 @@ void k_encode_tiles(TileArgs a) {
     // tile row of the strip already counted knows the strip's bits and adds its bytes (zero bits pad a strip to a byte,
     // encoder.h:442-443) to the frame's total.  Only the values the atomics return travel between tiles: no fence.
     auto strip_arrives = [&](uint32_t bits) -> unsigned long long {
+#ifdef M1V_TILE_NOCOMPLETE // timing build (wrong sizes): what the returning atomic and the completion cost
+        __hip_atomic_fetch_add(&a.strip_ctr[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], (1ull << kCtrCountShift) | (unsigned long long)bits,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0ull;
+#endif
         return atomicAdd(&a.strip_ctr[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], (1ull << kCtrCountShift) | (unsigned long long)bits);
     };
     auto strip_completes = [&](unsigned long long before, uint32_t bits) {
@@ -437,10 +442,11 @@ void k_encode_tiles(TileArgs a) {
     TSTAMP(7);
     lds_barrier();
     TSTAMP(8);
+    // (in front of the stores: the answer has been back since pass 2, and waiting for it here does not wait for the stores)
+    if (wave == 0 && lane < strips_here) strip_completes(arrived, seg_bits);
     uint32_t *slot32 = reinterpret_cast<uint32_t *>(a.scratch + tile_index * a.slot_bytes);
     for (uint32_t i = tid; i < end_words; i += kTileThreads) slot32[i] = __builtin_bswap32(image[i]);
     if (bad) atomicOr(a.status, (uint32_t)M1V_STATUS_UNENCODABLE);
-    if (wave == 0 && lane < strips_here) strip_completes(arrived, seg_bits);
     TSTAMP(9);
     TSTAMP_FLUSH();
 }
