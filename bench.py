@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: 1080p I-frames/s of the MPEG-1 I-frame hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1 via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts torch.distributed.run itself, as a child process)
 
 A step = one pass of the hot path over one batch of synthetic frames that are already resident in
 HBM (BASELINE.json configs[2]: 300 x 1920x1080, FULL region, quality factor 12): RGB in, contiguous
@@ -13,11 +13,14 @@ of one pinned host buffer), one host wait per step on eight pinned bytes per ran
 inside the loop.  Rank 0 prints ONE JSON line.
 
 The line's `roofline` prices the dominant kernel (k_encode_tiles for 3-channel input, k_encode_dense otherwise; --path
-forces one) against HBM with its time from HIP events recorded on
-the launch stream inside the library (per launch: min / median / max), carries the HBM bytes of the committed PMC
-passes (`traffic`, `pmc_fresh`), and says what the time is made of (`binding`, `valu`): see DESIGN.md, "Where the
-time goes".  `host_delivery`: the same steps with every batch's records delivered to pinned host memory under the
-next encode.  `cpu_baseline` is the oracle timed on this box's host cores (bounded samples).
+forces one) against HBM with its time from HIP events recorded on the launch stream inside the library (per launch:
+min / median / max) — `frac` — and the WHOLE step by the same formula — `step_frac` = algorithmic bytes x frames/s / peak
+(SURVEY 8d); it carries the HBM bytes of the committed PMC passes (`traffic`, `pmc_fresh`).  `sustained` is a second,
+longer leg (about 2.5 s of back-to-back steps) during which a child process samples socket power and shader clock
+(rocm-smi): what the chip holds when the run is long enough to sit at its power limit, and the vector-issue share of the
+kernel at THAT clock (`valu`).  `config4` = BASELINE config 4 (300 x 3840x2160) measured in the same process.
+`host_delivery`: the same steps with every batch's records delivered to pinned host memory under the next encode.
+`cpu_baseline` is the oracle timed on this box's host cores (bounded samples).
 """
 import argparse
 import json
@@ -30,6 +33,93 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS = 1024            # 256 CUs x 4 SIMDs; a wave's vector instruction issues over 2 cycles (same guide, "Wave scheduling")
+VALU_CYCLES_PER_INST = 2.0
+
+
+def launch_command(n_gpus, argv, port, script=None):
+    """The command `bench.py --gpus N` (N > 1) starts when it was not itself started by torch.distributed.run: one rank per
+    GPU of this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """N > 1 without WORLD_SIZE: run the ranks as a CHILD process group (never exec: the parent has not touched the GPU and does
+    not; the child's stdout — rank 0's JSON line — is this process's stdout) and leave with its return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(launch_command(n_gpus, argv, port), env=env).returncode
+
+
+class PowerSampler:
+    """Socket power and shader clock of one GPU while a leg of the benchmark runs: a child shell polls rocm-smi every ~0.1 s into
+    a temporary file (a child process: nothing in this process touches the SMU).  summary() = medians over the samples, or None
+    when rocm-smi is absent or prints nothing this parser knows."""
+
+    def __init__(self, device=0, seconds=6.0):
+        import shutil
+        import subprocess
+        import tempfile
+        self.proc = self.path = None
+        self.device = device
+        exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        if not exe:
+            return
+        fd, self.path = tempfile.mkstemp(prefix="ec504_power_")
+        os.close(fd)
+        loop = (f"{exe} -d {device} --showmaxpower 2>/dev/null; for i in $(seq 1 {int(seconds / 0.1)}); do echo @ $(date +%s.%N); "
+                f"{exe} -d {device} --showpower --showclocks 2>/dev/null; sleep 0.05; done")
+        self.proc = subprocess.Popen(["bash", "-c", loop], stdout=open(self.path, "w"), stderr=subprocess.DEVNULL)
+
+    def stop(self):
+        if self.proc:
+            self.proc.terminate()
+            try:
+                self.proc.wait(timeout=5)
+            except Exception:
+                self.proc.kill()
+            self.proc = None
+
+    def summary(self, t_begin, t_end):
+        """Medians over the samples taken in [t_begin, t_end] (time.time())."""
+        import re
+        import statistics
+        self.stop()
+        if not self.path:
+            return None
+        try:
+            text = open(self.path).read()
+        finally:
+            os.unlink(self.path)
+            self.path = None
+        cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
+        watts, mhz = [], []
+        for block in text.split("@ ")[1:]:
+            head, _, body = block.partition("\n")
+            try:
+                t = float(head.strip())
+            except ValueError:
+                continue
+            if not (t_begin <= t <= t_end):
+                continue
+            w = re.search(r"Package Power \(W\):\s*([0-9.]+)", body)
+            c = re.search(r"sclk clock level:[^\n]*\((\d+)Mhz\)", body)
+            if w:
+                watts.append(float(w.group(1)))
+            if c:
+                mhz.append(float(c.group(1)))
+        if not watts and not mhz:
+            return None
+        return {"power_w": round(statistics.median(watts), 1) if watts else None, "cap_w": float(cap.group(1)) if cap else None,
+                "sclk_mhz": round(statistics.median(mhz), 1) if mhz else None, "samples": max(len(watts), len(mhz)),
+                "source": "rocm-smi --showpower --showclocks polled by a child process during the leg (medians)"}
 
 
 def _host_cpu():
@@ -120,19 +210,22 @@ def pmc_traffic(rec):
     return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024) if rec else None
 
 
-def valu_roofline(rec, kernel_ms):
-    """How much of the kernel's time vector-ALU issue alone accounts for: (vector instructions per launch, PMC) x (what one
-    instruction of the kernel's own compiled stream costs a SIMD when nothing else is in the way: that stream looped
-    without memory at 5 waves per SIMD, profiles/r02_real_stream.txt) / SIMDs, against the live kernel time.  The rest of
-    the time is exposed memory latency at 5 waves per SIMD (without its pixel loads the kernel runs 13-15 % faster,
-    profiles/r02_ab_history.txt) and workgroup turnover; DESIGN.md, "Where the time goes"."""
+def valu_roofline(rec, kernel_ms, sclk_mhz=None):
+    """How much of the kernel's time vector-ALU issue alone accounts for: (vector instructions per launch, PMC) x 2 cycles (a
+    wave's vector instruction occupies its SIMD's issue port for two cycles, MI355X_MICROARCH.md) / 1024 SIMDs / the shader
+    clock — the clock rocm-smi showed during the sustained leg of this run, or, without one, the clock of the PMC pass — against
+    the kernel time.  The rest of the time is memory latency the waves in flight do not hide, and workgroup turnover."""
     if not rec or "valu" not in rec or kernel_ms <= 0:
         return None
     v = rec["valu"]
-    issue_ms = v["insts_per_launch"] * v["ns_per_inst_per_simd"] * 1e-6 / v["simds"]
+    ghz = sclk_mhz / 1e3 if sclk_mhz else v.get("clock_ghz")
+    if not ghz:
+        return None
+    issue_ms = v["insts_per_launch"] * VALU_CYCLES_PER_INST / SIMDS / (ghz * 1e9) * 1e3
     return {"bound": "valu-issue", "achieved": round(issue_ms, 4), "peak": round(kernel_ms, 4), "unit": "ms of issue per ms of kernel",
-            "frac": round(issue_ms / kernel_ms, 4), "insts_per_launch": v["insts_per_launch"],
-            "ns_per_inst_per_simd": v["ns_per_inst_per_simd"], "simds": v["simds"], "source": v.get("source", "")}
+            "frac": round(issue_ms / kernel_ms, 4), "insts_per_launch": v["insts_per_launch"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+            "simds": SIMDS, "sclk_ghz": round(ghz, 3), "sclk_source": "rocm-smi during the sustained leg" if sclk_mhz else "GRBM_GUI_ACTIVE of the PMC pass",
+            "source": "rocprofv3 --pmc SQ_INSTS_VALU (tools/pmc_r04.sh)"}
 
 
 def cli_bench(args):
@@ -205,6 +298,48 @@ def cli_bench(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def config4_leg(torch, Mpeg1Encoder, gpu_index, qf, seed, frames=300, warm=12, steps=30):
+    """BASELINE config 4 in the same process: 300 x 3840x2160 synthetic frames resident in HBM (7.5 GB), the same step loop, the
+    encode kernel's time from the library's events; `traffic` from the committed PMC record of this workload."""
+    W, H = 3840, 2160
+    dev = torch.device("cuda", gpu_index)
+    enc = Mpeg1Encoder(W, H, qf, "full", max_frames=frames, device=gpu_index)
+    try:
+        rgb = enc.synth(frames, seed=seed, first_frame_index=0, device=dev)
+        outs = [torch.empty(enc.default_out_capacity(frames), dtype=torch.uint8, device=dev) for _ in range(2)]
+        metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in outs]
+        sizes = torch.empty(frames, dtype=torch.int64, device=dev)
+        for k in range(warm):
+            enc.encode(rgb, 0, out=outs[k % 2], sizes=sizes, meta=metas[k % 2])
+        torch.cuda.synchronize(dev)
+        enc.profile(True)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            enc.encode(rgb, 0, out=outs[k % 2], sizes=sizes, meta=metas[k % 2])
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        times = enc.profile_read_times(cap=steps + 8)
+        enc.profile(False)
+        total, status = (int(x) for x in metas[(steps - 1) % 2].cpu())
+        assert (status & 0xFFFFFFFF) == 0, f"device status {status:#x}"
+        alg = 3 * W * H * frames + total
+        k_ms = sum(times) / max(len(times), 1)
+        fps = frames * steps / dt
+        pmc = _committed_pmc(W, H, frames, "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense")
+        traffic = pmc_traffic(pmc)
+        return {"workload": f"{frames} x {W}x{H} synthetic RGB frames, FULL region, quality_factor {qf}, input and output resident in HBM",
+                "value": round(fps, 1), "unit": "frames/s", "mpixels_per_s": round(fps * W * H / 1e6, 1), "steps": steps, "warmup": warm,
+                "ms_per_step": round(dt / steps * 1e3, 4), "bytes_out_per_frame": round(total / frames, 1),
+                "kernel": "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense", "kernel_ms": round(k_ms, 4),
+                "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit_roofline": "GB/s",
+                "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "step_frac": round(alg / frames * fps / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(alg),
+                "traffic": traffic, "traffic_over_algorithmic": round(traffic / alg, 4) if traffic else None,
+                "pmc_fresh": bool(pmc and pmc.get("fresh"))}
+    finally:
+        enc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +373,10 @@ def main():
                     help="which encode kernel serves the batches (include/mpeg1_hip.h, m1v_debug_set_path); auto = the library's choice")
     ap.add_argument("--cli", action="store_true",
                     help="instead of the headline run: time the folder-of-JPEGs CLI path end to end (SURVEY 8f.1/8f.2)")
+    ap.add_argument("--sustained-s", type=float, default=2.5,
+                    help="N=1: length of the second, sustained leg (back-to-back steps with socket power and shader clock sampled by a "
+                         "child rocm-smi poller); 0 = off.  Reported as `sustained`, never as `value`")
+    ap.add_argument("--no-config4", action="store_true", help="N=1: skip the 300 x 3840x2160 leg (BASELINE config 4, `config4`)")
     ap.add_argument("--cli-reference-frames", type=int, default=6)
     ap.add_argument("--cli-repeats", type=int, default=2)
     args = ap.parse_args()
@@ -245,6 +384,11 @@ def main():
         if args.frames == 300:
             args.frames = 128
         return cli_bench(args)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the driver starts it (python bench.py --gpus N ...): the ranks run as a child process group, this
+        # process never initialises the GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -256,8 +400,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with python bench.py --gpus N (it launches its ranks itself)")
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(--backend gloo rehearses the N > 1 code path on one GPU)")
     distributed = world > 1
     rehearsal = args.backend == "gloo"
     gpu_index = 0 if rehearsal else local_rank
@@ -350,11 +496,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if distributed:
+        dist.barrier()
     enc.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
+    if distributed:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_times = enc.profile_read_times(cap=max(args.steps, 1) + 8)
     launches, kernel_ms = len(kernel_times), float(sum(kernel_times))
@@ -379,7 +529,9 @@ def main():
         k_ms = kernel_ms / max(launches, 1)
         kernel_name = "k_encode_tiles" if enc.path == "tiles" else "k_encode_dense"
         pmc = _committed_pmc(W, H, n, kernel_name)
-        achieved = alg_bytes_frame * n / (k_ms * 1e-3) / 1e9 if launches else 0.0
+        alg_bytes = alg_bytes_frame * n
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if launches else 0.0
+        step_achieved = alg_bytes_frame * fps / world / 1e9       # per GPU: SURVEY 8(d), algorithmic bytes x frames/s
         line = {
             "metric": "1080p I-frames/s" if (W, H) == (1920, 1080) else f"{W}x{H} I-frames/s",
             "mpixels_per_s_definition": "frames/s x W x H / 1e6",
@@ -390,22 +542,47 @@ def main():
             "dtype": "f32 (colour fast path, FDCT: exact integers in floats) + f64 (colour ties) + int32 (VLC, packing)",
             "data": "synthetic",
             "config": {"workload": f"{n} x {W}x{H} synthetic RGB frames per GPU, FULL region (all macroblocks), quality_factor {qf}, "
-                                   "input and output resident in HBM" + ("" if distributed or not args.pipeline else "; batch k's gather overlaps batch k+1's encode (two output buffers)"), "frames_per_gpu": n,
+                                   "input and output resident in HBM" + ("" if distributed or not args.pipeline else "; batch k's assembly overlaps batch k+1's encode (two output buffers)"), "frames_per_gpu": n,
                        "global_frames": n * world, "bytes_out_per_frame": round(out_per_frame, 1),
                        "parallelism": f"frames sharded {n}/GPU" + (
                            (", grouped send/recv of the bitstreams to rank 0 (RCCL)" if args.gather == "xgmi" else
                             ", every rank copies its bitstream into its slice of one pinned host buffer") if distributed else "")},
-            # "hbm" is the roofline BASELINE.json prices the path against.  What the time is made of today: vector-ALU issue
-            # ("valu": ~0.8 of the kernel time) plus memory latency that 5 waves per SIMD do not hide
+            # "hbm" is the roofline BASELINE.json prices the path against: `frac` = the dominant kernel alone, `step_frac` = the whole
+            # step (encode + assembly; per GPU).  What the kernel's time is made of is measured in the `sustained` leg below.
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(pmc),
-                         "pmc_fresh": bool(pmc and pmc.get("fresh")), "l1_to_l2_read_requests_per_pixel_line": round(pmc["l1_to_l2_read_requests"] / pmc["pixel_lines_128B"], 3) if pmc else None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "step_achieved": round(step_achieved, 2), "step_frac": round(step_achieved / HBM_PEAK_GBS, 5),
+                         "traffic": pmc_traffic(pmc), "pmc_fresh": bool(pmc and pmc.get("fresh")),
+                         "l1_to_l2_read_requests_per_pixel_line": round(pmc["l1_to_l2_read_requests"] / pmc["pixel_lines_128B"], 3)
+                         if pmc and pmc.get("l1_to_l2_read_requests") and pmc.get("pixel_lines_128B") else None,
                          "kernel_ms": round(k_ms, 4), "kernel_ms_min": round(min(kernel_times), 4) if kernel_times else None,
                          "kernel_ms_median": round(float(np.median(kernel_times)), 4) if kernel_times else None,
                          "kernel_ms_max": round(max(kernel_times), 4) if kernel_times else None, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": int(alg_bytes_frame * n), "binding": "package power: a sustained run holds the 1400 W cap at ~2.1-2.3 of 2.4 GHz (profiles/r03_power_trace.txt), so the kernel is timed by the energy of its vector instructions (~0.8 of the kernel time is VALU issue); neither kernel waits for HBM (frames resident in the Infinity Cache run no faster)",
-                         "valu": valu_roofline(pmc, k_ms)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if world == 1 and args.sustained_s > 0:
+            # A run long enough to sit at the package power limit: the same steps for ~args.sustained_s seconds, wall clock only
+            # (no event records: two per launch would leave gaps in which the chip boosts), power and clock sampled by a child.
+            k_sus = max(args.steps, int(args.sustained_s / (ms_per_step * 1e-3)))
+            sampler = PowerSampler(gpu_index, seconds=args.sustained_s + 4.0)
+            time.sleep(0.4)                              # (the poller's first rocm-smi call)
+            w_b = time.time()
+            t0 = time.perf_counter()
+            for _ in range(k_sus):
+                step()
+            fence()
+            dt = time.perf_counter() - t0
+            w_e = time.time()
+            power = sampler.summary(w_b + min(0.5, 0.25 * dt), w_e)
+            sus_fps = n * k_sus / dt
+            line["sustained"] = {"value": round(sus_fps, 1), "unit": "frames/s", "steps": k_sus, "ms_per_step": round(dt / k_sus * 1e3, 4),
+                                 "step_frac": round(alg_bytes_frame * sus_fps / 1e9 / HBM_PEAK_GBS, 5), "power": power,
+                                 "note": "the headline steps repeated back to back for this long; `value` above is the run the driver asked for"}
+            line["roofline"]["valu"] = valu_roofline(pmc, k_ms, power["sclk_mhz"] if power and power.get("sclk_mhz") else None)
+        else:
+            line["roofline"]["valu"] = valu_roofline(pmc, k_ms)
+        if world == 1 and not args.no_config4 and (W, H) == (1920, 1080) and args.path == "auto":
+            line["config4"] = config4_leg(torch, Mpeg1Encoder, gpu_index, qf, seed)
         if world == 1 and not args.no_cpu_baseline:
             head = out[:min(out.numel(), 4 * (W * H // 2))].cpu().numpy().tobytes()   # first frame records of rank 0
             line["cpu_baseline"] = cpu_baseline(W, H, qf, seed, gpu_head=head)
@@ -415,19 +592,32 @@ def main():
             # records of batch k copied to one of two pinned buffers while batch k+1 encodes
             from ec504_imageencoder_amd.delivery import HostDelivery
             hd = HostDelivery(enc, n, capacity=outs[0].numel())
-            for _ in range(max(4, args.warmup // 4)):
+            # its own step counts, whatever the headline's were: pinned buffers are first touched, and the copy engine's
+            # queue fills, over the first ~16 steps (a 20-step run behind 4 warm-up steps measured 0.84 of the resident rate,
+            # the same loop behind 50 steps 0.96)
+            hd_warm, hd_steps, chunk = max(16, args.warmup), max(100, args.steps), 20
+            for _ in range(hd_warm):
                 hd.step(rgb, first)
             hd.fence()
             hd.bytes_delivered = 0
+            chunk_ms = []
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for k in range(hd_steps):
+                if k % chunk == 0:
+                    tc = time.perf_counter()
                 hd.step(rgb, first)
+                if k % chunk == chunk - 1:
+                    chunk_ms.append((time.perf_counter() - tc) / chunk * 1e3)
             hd.fence()
             dt = time.perf_counter() - t0
             same = bool(torch.equal(hd.result(), outs[(step_no - 1) % len(outs)][:total_bytes].cpu()))
-            line["host_delivery"] = {"value": round(n * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
-                                     "pcie_gb_per_s": round(hd.bytes_delivered / dt / 1e9, 2), "bytes_per_step": hd.bytes_delivered // args.steps,
-                                     "holds_device_resident_rate": round(n * args.steps / dt / fps, 4),
+            line["host_delivery"] = {"value": round(n * hd_steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / hd_steps * 1e3, 4),
+                                     "steps": hd_steps, "warmup": hd_warm,
+                                     "ms_per_step_min_of_20": round(min(chunk_ms), 4) if chunk_ms else None,
+                                     "ms_per_step_median_of_20": round(float(np.median(chunk_ms)), 4) if chunk_ms else None,
+                                     "pcie_gb_per_s": round(hd.bytes_delivered / dt / 1e9, 2), "bytes_per_step": hd.bytes_delivered // hd_steps,
+                                     "holds_device_resident_rate": round(n * hd_steps / dt / fps, 4),
+                                     "holds_sustained_rate": round(n * hd_steps / dt / line["sustained"]["value"], 4) if "sustained" in line else None,
                                      "delivered_equals_device_output": same,
                                      "note": "input resident in HBM; frame records of batch k -> pinned host memory on a side stream while batch "
                                              "k+1 encodes (ec504_imageencoder_amd/delivery.py); one host wait per step on 16 pinned bytes"}

@@ -5,7 +5,8 @@ contiguous host bitstream"; the reference writes it with bitvector_fwrite, inclu
 records travel device-to-host on a side stream into one of two pinned buffers.  The copy needs the batch's byte count on
 the host, so once per step the host waits for ONE event — "the 16 bytes (total, status) of batch k have reached pinned
 memory" — and at that moment the main stream already holds the encode of batch k+1.  Nothing is allocated inside the loop.
-A batch whose status word is not zero is not delivered: step() raises.
+A batch that ran out of overflow scratch (M1V_STATUS_SCRATCH, recoverable) is encoded again with the worst case reserved, as
+sharding.StepPipeline does; a batch with any other status bit is not delivered: step() raises.
 """
 from . import _ffi
 
@@ -25,6 +26,7 @@ class HostDelivery:
         self.encoded = [torch.cuda.Event() for _ in range(n_buffers)]
         self.counted = [torch.cuda.Event() for _ in range(n_buffers)]
         self.delivered = [None] * n_buffers
+        self.args = [None] * n_buffers   # what buffer b was encoded from (for the scratch retry)
         self.pending, self.step_no = [], 0
         self.last = None            # (buffer index, total bytes) of the newest delivered batch
         self.bytes_delivered = 0
@@ -37,6 +39,14 @@ class HostDelivery:
             self.counted[b].record(self.side)
             self.counted[b].synchronize()       # the step's only host wait; the next encode is already queued
             total, status = int(self.host_meta[b][0]), int(self.host_meta[b][1]) & 0xFFFFFFFF
+            if status == _ffi.STATUS_SCRATCH and self.args[b] is not None:
+                # recoverable: reserve the worst case (waits for the device), encode the same frames again on this stream
+                rgb, first = self.args[b]
+                self.enc.reserve_scratch(True)
+                self.enc.encode(rgb, first, out=self.outs[b], sizes=self.sizes[b], meta=self.metas[b])
+                self.host_meta[b].copy_(self.metas[b], non_blocking=True)
+                self.side.synchronize()
+                total, status = int(self.host_meta[b][0]), int(self.host_meta[b][1]) & 0xFFFFFFFF
             if status:
                 raise RuntimeError(f"encode status {status:#x}: the batch's output is undefined and is not delivered")
             if total > self.host[b].numel():
@@ -56,6 +66,7 @@ class HostDelivery:
             self.torch.cuda.current_stream().wait_event(self.delivered[b])   # buffer b has left for the host: free again
         self.enc.encode(rgb, first_frame_index, out=self.outs[b], sizes=self.sizes[b], meta=self.metas[b])
         self.encoded[b].record()
+        self.args[b] = (rgb, first_frame_index)
         self.pending.append(b)
         if len(self.pending) > 1:
             self._deliver(self.pending.pop(0))
