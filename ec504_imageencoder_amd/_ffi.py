@@ -19,13 +19,15 @@ _u8p = C.POINTER(C.c_uint8)
 # every symbol include/mpeg1_hip.h declares (tests check that the library exports all of them)
 MPEG1_HIP_SYMBOLS = [
     "m1v_device_count", "m1v_warm_up", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
-    "m1v_frame_bound", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
+    "m1v_frame_bound", "m1v_frame_bound_for", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
     "m1v_encode_planes_host",
     "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_profile_read_times", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
     "m1v_debug_set_input_mode", "m1v_reserve_scratch", "m1v_scratch_bytes", "m1v_debug_set_path", "m1v_path_in_use", "m1v_debug_fail_alloc",
+    "m1v_delivery_create", "m1v_delivery_destroy", "m1v_delivery_step", "m1v_delivery_flush", "m1v_delivery_wait", "m1v_delivery_bytes",
 ]
+DELIVERY_NONE = 2
 
 
 ENCODER_H_SYMBOLS = ["mpeg_encode_procedure", "mpeg_encode_procedure_region", "encoder_set_image_loader",
@@ -111,6 +113,18 @@ def lib():
     L.m1v_path_in_use.restype = C.c_int
     L.m1v_debug_fail_alloc.argtypes = [C.c_int]
     L.m1v_debug_fail_alloc.restype = None
+    L.m1v_delivery_create.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.m1v_delivery_create.restype = C.c_int
+    L.m1v_delivery_destroy.argtypes = [vp]
+    L.m1v_delivery_destroy.restype = None
+    L.m1v_delivery_step.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.m1v_delivery_step.restype = C.c_int
+    L.m1v_delivery_flush.argtypes = [vp]
+    L.m1v_delivery_flush.restype = C.c_int
+    L.m1v_delivery_wait.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp)]
+    L.m1v_delivery_wait.restype = C.c_int
+    L.m1v_delivery_bytes.argtypes = [vp, C.c_int]
+    L.m1v_delivery_bytes.restype = C.c_uint64
     L.mpeg_encode_procedure.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
     L.mpeg_encode_procedure.restype = C.c_int
     L.mpeg_encode_procedure_region.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]

@@ -15,12 +15,14 @@
  *   EC504_DEVICES=<a,b,...>           one GPU encoder per entry, chunk c goes to entry c mod N; the same index may
  *                                     appear more than once (default "<d>,<d>", d = EC504_DEVICE: two encoders on one
  *                                     GPU, so that one chunk's upload runs under the other's kernels and downloads)
- *   EC504_KEEP_ENCODER=0              do not keep the GPU encoders and pinned buffers for the next call (default: keep;
- *                                     encoder_release_cache() frees them)
+ *   EC504_KEEP_ENCODER=0              do not keep the GPU encoders and pinned buffers for the next call (default: keep ONE
+ *                                     set — the last call's; a call that asks for something else frees it first;
+ *                                     encoder_release_cache() and process exit free it)
  *   EC504_BATCH=<n>                   frames per device batch                  (default 64)
- *   EC504_HOST_THREADS=<n>            decode / staging / .bit-writer threads   (default: online CPUs, <= 64;
- *                                     1 = everything on the calling thread, as the reference)
+ *   EC504_HOST_THREADS=<n>            decode / staging / .bit-writer threads   (default: the CPUs this process may run
+ *                                     on, <= 512; 1 = everything on the calling thread, as the reference)
  */
+#define _GNU_SOURCE
 #define _DEFAULT_SOURCE
 #define EC504_NO_STB
 #include "encoder.h"
@@ -28,6 +30,7 @@
 
 #include <errno.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 #include <time.h>
@@ -149,6 +152,22 @@ static void group_start(Pool *p, Group *g, void (*fn)(void *, int), void *ctx, i
     pthread_mutex_unlock(&p->mu);
 }
 
+/* The same, in FRONT of everything queued (the set-up work a whole pipeline waits for must not queue behind 200 decodes). */
+static void group_start_front(Pool *p, Group *g, void (*fn)(void *, int), void *ctx, int n) {
+    g->fn = fn;
+    g->ctx = ctx;
+    g->n = n;
+    g->next = g->done = 0;
+    g->link = NULL;
+    if (n <= 0) return;
+    pthread_mutex_lock(&p->mu);
+    g->link = p->head;
+    p->head = g;
+    if (!p->tail) p->tail = g;
+    pthread_cond_broadcast(&p->work);
+    pthread_mutex_unlock(&p->mu);
+}
+
 /* Returns when every task of g has run — or, with a flag, as soon as *flag is set (under p->mu, with a
  * broadcast on p->idle); the caller runs queued tasks (of any group) meanwhile. */
 static void group_wait_or(Pool *p, Group *g, const int *flag) {
@@ -205,6 +224,16 @@ typedef struct {
     uint8_t *dst;  /* pinned batch buffer */
     size_t frame_in;
 } StageJob;
+
+typedef struct {
+    void **dst;
+    size_t bytes;
+} AllocItem;
+
+static void alloc_task(void *ctx, int i) { /* one pinned buffer (page-locking ~100 MB takes tens of milliseconds: in parallel) */
+    AllocItem *a = (AllocItem *)ctx + i;
+    *a->dst = m1v_alloc_host(a->bytes);
+}
 
 static void stage_task(void *ctx, int i) {
     StageJob *j = (StageJob *)ctx;
@@ -338,11 +367,12 @@ static double now_s(void) {
 
 static int host_threads(void) {
     int n = env_int("EC504_HOST_THREADS", g_threads);
-    if (n <= 0) {
-        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n <= 0) { /* the CPUs this process may run on (a container's share), not the machine's */
+        cpu_set_t set;
+        long cpus = sched_getaffinity(0, sizeof set, &set) == 0 ? (long)CPU_COUNT(&set) : sysconf(_SC_NPROCESSORS_ONLN);
         n = cpus < 1 ? 1 : (int)cpus;
     }
-    return n > 64 ? 64 : n;
+    return n > 512 ? 512 : n;
 }
 
 int mpeg_encode_procedure_region(const char *images_folder, const char *bitstream_folder,
@@ -413,7 +443,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
      * loads and checks EVERYTHING before it encodes (encoder.h:140-183); a folder it would reject is
      * recognised here when the offending file is reached, and whatever was written until then is taken back
      * (video truncated to its 27-byte prolog, side files removed), which is the state the reference leaves. */
-    enum { RING = 16 }; /* decode groups in flight, at most RING-1 chunks ahead of the GPU */
+    enum { RING = 48 }; /* decode groups in flight, at most RING-1 chunks ahead of the GPU */
     int rc = -1, mismatch = 0;
     const int timing = env_int("EC504_TIMING", 0); /* phase times on stderr */
     double t_phase[5] = {now_s(), 0, 0, 0, 0}, t_created = 0;
@@ -470,8 +500,8 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     if (batch > n_paths - head) batch = n_paths - head;
     const int n_chunks = (n_paths - head + batch - 1) / batch;
     if (cx.n_lanes > n_chunks) cx.n_lanes = n_chunks; /* no more encoders than chunks */
-    const int N = cx.n_lanes;
-    /* enough chunks of decoding in flight to keep every thread busy (1.5 files per thread), 2..15 */
+    int N = cx.n_lanes; /* (may still shrink: a lane whose encoder cannot be created is dropped) */
+    /* enough chunks of decoding in flight to keep every thread busy (1.5 files per thread), 2..47 */
     int look = (3 * (pool.n_threads + 1) / 2 + batch - 1) / batch;
     look = look < N + 1 ? N + 1 : look;
     look = look > RING - 1 ? RING - 1 : look;
@@ -500,37 +530,58 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     if (context_matches(&g_cache, &cx)) {
         cx = g_cache; /* (batch, slots and planes may be larger than asked for) */
         memset(&g_cache, 0, sizeof g_cache);
+    } else if (g_cache.valid) {
+        context_free(&g_cache); /* one set at a time: the old encoders and pinned buffers go before the new ones come */
     }
     pthread_mutex_unlock(&g_cache_mu);
     size_t bound = 0;
     if (!cx.valid) {
-        for (int l = 0; l < N && alloc_ok; l++) {
+        /* pinned staging (copies to and from the GPU then run at the PCIe rate), page-locked by the pool IN FRONT of the
+         * queued decodes while this thread creates the encoders.  A lane's output buffer starts at 1/16 of the worst case
+         * (white noise needs about 1/46 of it, pictures built to be expensive about 1/11) and grows on demand (see below). */
+        AllocItem items[3 * MAX_LANES + 2];
+        int n_items = 0;
+        Group allocs;
+        memset(&allocs, 0, sizeof allocs);
+        bound = m1v_frame_bound_for(W, H, region ? M1V_MODE_FULL : M1V_MODE_STRICT);
+        for (int l = 0; l < N; l++) {
+            cx.lane[l].out_cap = bound * ((size_t)batch + 1) / 16;
+            items[n_items++] = (AllocItem){(void **)&cx.lane[l].out, cx.lane[l].out_cap};
+        }
+        for (int s = 0; s < cx.n_slots; s++) {
+            items[n_items++] = (AllocItem){(void **)&cx.batch_in[s], frame_in * (size_t)batch};
+            if (write_bit) items[n_items++] = (AllocItem){(void **)&cx.planes[s], frame_planes * (size_t)batch};
+        }
+        group_wait(&pool, &warm); /* (the runtime of every device in the list is up: page-locking needs one) */
+        group_start_front(&pool, &allocs, alloc_task, items, n_items);
+        cx.valid = 1; /* from here on: whatever exists is freed by context_free */
+        for (int l = 0; l < N; l++) {
+            cx.lane[l].sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
             if (m1v_create(&cx.lane[l].enc, cx.devices[l], W, H, C, quality_factor, region ? M1V_MODE_FULL : M1V_MODE_STRICT,
                            batch) != M1V_OK) {
-                printf("Error: cannot set up the GPU encoder: %s\n", m1v_last_error());
                 cx.lane[l].enc = NULL;
-                alloc_ok = 0;
-                cx.valid = 1; /* so that what exists is freed */
-                goto done;
+                if (l == 0) {
+                    printf("Error: cannot set up the GPU encoder: %s\n", m1v_last_error());
+                    alloc_ok = 0;
+                } else {
+                    printf("Note: encoder %d of %d could not be created (%s): continuing with %d\n", l + 1, N, m1v_last_error(), l);
+                }
+                group_wait(&pool, &allocs);
+                for (int k = l; k < N; k++) { /* the lanes that will not run give their buffers back */
+                    m1v_free_host(cx.lane[k].out);
+                    free(cx.lane[k].sizes);
+                    cx.lane[k].out = NULL;
+                    cx.lane[k].sizes = NULL;
+                }
+                cx.n_lanes = N = l;
+                break;
             }
         }
         t_created = now_s();
-        bound = m1v_frame_bound(cx.lane[0].enc);
-        /* pinned staging (copies to and from the GPU then run at the PCIe rate).  A lane's output buffer starts at 1/16 of
-         * the worst case (white noise needs about 1/46 of it, pictures built to be expensive about 1/11) and grows on
-         * demand (see below). */
-        for (int l = 0; l < N; l++) {
-            cx.lane[l].out_cap = bound * ((size_t)batch + 1) / 16;
-            cx.lane[l].out = (uint8_t *)m1v_alloc_host(cx.lane[l].out_cap);
-            cx.lane[l].sizes = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)batch);
-            alloc_ok = alloc_ok && cx.lane[l].out && cx.lane[l].sizes;
-        }
-        for (int s = 0; s < cx.n_slots; s++) {
-            cx.batch_in[s] = (uint8_t *)m1v_alloc_host(frame_in * (size_t)batch);
-            if (write_bit) cx.planes[s] = (uint8_t *)m1v_alloc_host(frame_planes * (size_t)batch);
-            alloc_ok = alloc_ok && cx.batch_in[s] && (!write_bit || cx.planes[s]);
-        }
-        cx.valid = 1;
+        group_wait(&pool, &allocs);
+        if (N == 0) goto done;
+        for (int l = 0; l < N; l++) alloc_ok = alloc_ok && cx.lane[l].out && cx.lane[l].sizes;
+        for (int s = 0; s < cx.n_slots; s++) alloc_ok = alloc_ok && cx.batch_in[s] && (!write_bit || cx.planes[s]);
     } else {
         t_created = now_s();
         bound = m1v_frame_bound(cx.lane[0].enc);
@@ -642,8 +693,11 @@ done:
         for (int l = 0; keep && l < cx.n_lanes; l++) keep = cx.lane[l].enc && cx.lane[l].out && cx.lane[l].sizes;
         pthread_mutex_lock(&g_cache_mu);
         if (keep) {
+            static int at_exit_registered = 0;
             if (g_cache.valid) context_free(&g_cache);
             g_cache = cx;
+            /* given back at process exit too (registered now, i.e. after the GPU runtime's own exit handlers: runs before them) */
+            if (!at_exit_registered && atexit(encoder_release_cache) == 0) at_exit_registered = 1;
         } else {
             context_free(&cx);
         }

@@ -441,60 +441,6 @@ __device__ __forceinline__ void block_bits_pass1(uint32_t hdr, int hlen, bool dc
     tot += 2;
 }
 
-// The same pass, TWO coded coefficients per trip.  What a wave pays for in this loop is not instructions but LDS round
-// trips: a coefficient needs its staged level and its row of the offset index (independent of each other), then the table
-// entry they select — two dependent LDS latencies, and a wave takes as many trips as its longest lane has coefficients
-// (4-6 on noise at quality 12).  The second coefficient's position and run come from the mask alone, so its reads go out
-// with the first one's: half the trips.  A lane without a second coefficient repeats the first (valid addresses) and adds
-// zero bits.
-template <bool NARROW, typename Fetch>
-__device__ __forceinline__ void block_bits_pass1_pairs(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
-                                                       const uint32_t *vlc, Fetch fetch, unsigned long long &acc, int &tot,
-                                                       uint32_t &bad) {
-    acc = hdr;
-    tot = hlen;
-    int prev = dc_nonzero ? 0 : -1;
-    while (emit) {
-        const int pa = __builtin_ctzll(emit);
-        emit &= emit - 1;
-        const bool two = emit != 0;
-        const int pb = two ? __builtin_ctzll(emit) : pa;
-        emit &= emit - 1; // 0 & -1 stays 0
-        const int ra = pa - prev - 2, rb = two ? pb - pa - 2 : ra;
-        prev = pb;
-        // round 1: both levels, both index rows
-        const int la = fetch(pa), lb = fetch(pb);
-        const uint32_t ia = vlc[kVlcRowInfo + min(ra, kAcRows - 1)], ib = vlc[kVlcRowInfo + min(rb, kAcRows - 1)];
-        const uint32_t La = (uint32_t)(la < 0 ? -la : la), Lb = (uint32_t)(lb < 0 ? -lb : lb);
-        const bool ta = ra < kAcRows && La - 1u < (ia >> 8), tb = rb < kAcRows && Lb - 1u < (ib >> 8);
-        // round 2: both entries
-        const uint32_t ea = vlc[kVlcEntries + (ta ? (ia & 0xffu) + La - 1u : 0u)], eb = vlc[kVlcEntries + (tb ? (ib & 0xffu) + Lb - 1u : 0u)];
-        auto finish = [&](int r, int level, uint32_t L, bool in_table, uint32_t e, uint32_t &code, uint32_t &bits) {
-            const uint32_t head = (1u << 6) | ((uint32_t)r & 0x3fu); // "000001" + 6-bit run (vlc.c:346-381)
-            const uint32_t lo = (uint32_t)level & 0xffu;
-            uint32_t esc = (head << 8) | lo, esc_bits = 20;
-            if (!NARROW) {
-                const bool wide = L >= 128u;
-                esc = wide ? (head << 16) | (level < 0 ? 0x8000u : 0u) | lo : esc;
-                esc_bits = wide ? 28 : 20;
-                bad |= (!in_table && L >= 256u) ? 1u : 0u;
-            }
-            code = in_table ? (e & 0xffffu) : esc;
-            bits = in_table ? (e >> 16) : esc_bits;
-        };
-        uint32_t ca, ba, cb, bbits;
-        finish(ra, la, La, ta, ea, ca, ba);
-        finish(rb, lb, Lb, tb, eb, cb, bbits);
-        acc = (acc << ba) | ca;
-        tot += (int)ba;
-        bbits = two ? bbits : 0u;
-        acc = (acc << bbits) | (two ? cb : 0u);
-        tot += (int)bbits;
-    }
-    acc = (acc << 2) | 0x2u; // EOB "10", mpeg1_blk.c:115-117
-    tot += 2;
-}
-
 // The same walk, code word by code word into `sink` (pass 2 of the rare blocks that exceed 64 bits).
 template <bool NARROW, typename Fetch, typename Sink>
 __device__ __forceinline__ void walk_codes(uint32_t hdr, int hlen, bool dc_nonzero, unsigned long long emit,
@@ -696,16 +642,9 @@ __device__ __forceinline__ Row24 row_bytes(const Row28 &v, const uint8_t *p) {
     for (int k = 0; k < 6; k++) r.d[k] = __builtin_amdgcn_alignbyte(v.d[k + 1], v.d[k], m);
     return r;
 }
-// Rows kLate24 .. 7 of the aligned 3-channel mode are requested from inside the row loop (once row 0 has been consumed):
-// with the row outputs packed (RowStore) the pixel stage fits 80 VGPRs only if not all 48 raw registers are in flight at
-// its start.  Rows 6 and 7 late measured no slower than all eight up front (profiles/r02_ab_history.txt: 618.6 vs 621.3 us).
-#ifndef M1V_DENSE_LATE
-#define M1V_DENSE_LATE 8
-#endif
-constexpr int kLate24 = M1V_DENSE_LATE;
 __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const BlockSrc &src, Row24 raw[8]) {
 #pragma unroll
-    for (int i = 0; i < kLate24; i++)
+    for (int i = 0; i < 8; i++)
         raw[i] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u));
 }
 
@@ -714,14 +653,14 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *fbase, const Bloc
 // The 64 outputs of the row pass, held until the column pass.  Columns KEEP..7 are stored as f16 PAIRS: every row output
 // except column 0 (the plain sum, which also carries the pixel bias 8 * 256) is an integer of magnitude <= 1020, the sum
 // without its bias one of magnitude <= 2040 (fdct_f32.h; tools/fdct_f32_proof.cpp checks the bounds), and f16 holds every
-// integer up to 2048 exactly, so packing (v_cvt_pkrtz_f16_f32) and unpacking (v_cvt_f32_f16) lose nothing.  KEEP = 0
-// packs all eight columns (the bias comes off column 0 first): 32 registers instead of 64, which is what lets the pixel
-// stage fit 80 VGPRs = 6 waves per SIMD, where the unpacked form needs 96 (5).
+// integer up to 2048 exactly, so packing (v_cvt_pkrtz_f16_f32) and unpacking (v_cvt_f32_f16) lose nothing.  Column 0 always
+// stays a float (KEEP >= 2).  All eight columns packed (66 VGPRs, 6 waves per SIMD) measured 0.3-2.6 % slower in a sustained
+// run than all eight unpacked at 5 waves (profiles/r03_ab_history.txt) and was removed in round 4.
 typedef __fp16 m1v_h2 __attribute__((ext_vector_type(2)));
 template <int KEEP>
 struct RowStore {
-    static_assert(KEEP >= 0 && KEEP <= 8 && (8 - KEEP) % 2 == 0, "pairs of columns are packed");
-    static constexpr float kBias0 = KEEP == 0 ? 0.0f : 8.0f * m1vf::kPxBiasF; // what column 0 still carries on top of the sum
+    static_assert(KEEP >= 2 && KEEP <= 8 && (8 - KEEP) % 2 == 0, "pairs of columns are packed; column 0 stays a float");
+    static constexpr float kBias0 = 8.0f * m1vf::kPxBiasF; // what column 0 still carries on top of the sum
     float f[8][KEEP + 1];
     m1v_h2 h[8][(8 - KEEP) / 2 + 1];
     __device__ __forceinline__ void put(int r, const float out[8]) {
@@ -729,7 +668,7 @@ struct RowStore {
         for (int c = 0; c < KEEP; c++) f[r][c] = out[c];
 #pragma unroll
         for (int c = KEEP; c < 8; c += 2) {
-            m1v_h2 v = __builtin_amdgcn_cvt_pkrtz(c == 0 ? out[0] - 8.0f * m1vf::kPxBiasF : out[c], out[c + 1]);
+            m1v_h2 v = __builtin_amdgcn_cvt_pkrtz(out[c], out[c + 1]);
             // pinned here (volatile statements keep their order, and the next row's LDS read is one): left to itself the
             // scheduler sinks all packing behind the last row and the unpacked values spill
             asm volatile("" : "+v"(v));
@@ -751,8 +690,6 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
     CompCoefF k = comp_coef_f(src.comp());
     Row32 late[FAST == 3 ? 4 : 1];
     (void)late;
-    Row24 late24[FAST == 1 && kLate24 < 8 ? 8 - kLate24 : 1];
-    (void)late24;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         float px[8];
@@ -763,13 +700,6 @@ __device__ __forceinline__ int block_to_stage(const Geometry &g, const uint8_t *
                     late[r] = *reinterpret_cast<const Row32 *>(fbase + (size_t)((src.first + (uint32_t)(r + 4) * src.stride) * 4u));
             }
             convert_row<4, true>(i < 4 ? raw[i] : late[i - 4], k, px);
-        } else if constexpr (FAST == 1 && kLate24 < 8) {
-            if (i == 1) {
-#pragma unroll
-                for (int r = kLate24; r < 8; r++)
-                    late24[r - kLate24] = *reinterpret_cast<const Row24 *>(fbase + (size_t)((src.first + (uint32_t)r * src.stride) * 3u));
-            }
-            convert_row<3, false>(i < kLate24 ? raw[i] : late24[i - kLate24], k, px);
         } else if constexpr (FAST != 0) {
             convert_row<3, FAST == 2>(row_bytes(raw[i], fbase + (size_t)((src.first + (uint32_t)i * src.stride) * 3u)), k, px);
         } else {
@@ -1772,11 +1702,18 @@ static int configure_path(m1v_encoder *e) {
     }
     const int sets = e->pipelined ? 2 : 1;
     segb = (size_t)e->max_frames * g.n_strips * segs * sizeof(uint2);
+    // ---- allocate EVERYTHING the new plan needs first (every device allocation through plan_malloc: the fault-injection hook
+    //      reaches all of them); nothing of the encoder is touched until all of it is there ----
     struct Fresh {
         uint8_t *scratch;
         void *meta, *seg;
-        bool new_scratch, new_meta, new_seg;
+        bool new_scratch, new_meta, new_seg, new_fixed;
+        m1v_encoder::Counters ctr[2];
+        hipEvent_t enc_done, gather_done;
     } fresh[2] = {};
+    uint32_t *fresh_order = nullptr;
+    const bool new_order = plan.tiles && e->tile_order_rows != plan.tile_rows;
+    const size_t nslots = (size_t)e->max_frames * g.n_strips;
     bool ok = true;
     for (int i = 0; i < sets && ok; i++) {
         const m1v_encoder::Batch &bt = e->batch[i];
@@ -1784,19 +1721,46 @@ static int configure_path(m1v_encoder *e) {
         f.new_scratch = need != e->scratch_bytes || !bt.scratch;
         f.new_meta = meta != 0 && (meta != e->meta_bytes || !bt.run_meta);
         f.new_seg = segb != 0 && (segb != e->seg_bytes || !bt.seg);
+        f.new_fixed = !bt.enc_done;
         if (f.new_scratch) ok = plan_malloc((void **)&f.scratch, need) == hipSuccess;
         if (ok && f.new_meta) ok = plan_malloc(&f.meta, meta) == hipSuccess;
         if (ok && f.new_seg) ok = plan_malloc(&f.seg, segb) == hipSuccess;
+        if (ok && f.new_fixed) {
+            for (m1v_encoder::Counters &c : f.ctr) {
+                ok = ok && plan_malloc((void **)&c.strip_ctr, nslots * 8) == hipSuccess && hipMemset(c.strip_ctr, 0, nslots * 8) == hipSuccess;
+                ok = ok && plan_malloc((void **)&c.frame_bytes, (size_t)e->max_frames * 8) == hipSuccess &&
+                     hipMemset(c.frame_bytes, 0, (size_t)e->max_frames * 8) == hipSuccess;
+                ok = ok && plan_malloc((void **)&c.words, 4 * sizeof(uint32_t)) == hipSuccess && hipMemset(c.words, 0, 4 * sizeof(uint32_t)) == hipSuccess;
+                c.dirty_frames = 0;
+            }
+            ok = ok && hipEventCreateWithFlags(&f.gather_done, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&f.enc_done, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    if (ok && new_order) {
+        std::vector<uint32_t> order;
+        tile_row_order_for(plan.tile_rows, order);
+        ok = plan_malloc((void **)&fresh_order, order.size() * sizeof(uint32_t)) == hipSuccess &&
+             hipMemcpy(fresh_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) {
         for (Fresh &f : fresh) {
             (void)hipFree(f.scratch);
             (void)hipFree(f.meta);
             (void)hipFree(f.seg);
+            for (m1v_encoder::Counters &c : f.ctr) {
+                (void)hipFree(c.strip_ctr);
+                (void)hipFree(c.frame_bytes);
+                (void)hipFree(c.words);
+            }
+            if (f.enc_done) (void)hipEventDestroy(f.enc_done);
+            if (f.gather_done) (void)hipEventDestroy(f.gather_done);
         }
+        (void)hipFree(fresh_order);
         (void)hipGetLastError();
-        return fail(M1V_E_HIP, "scratch allocation failed (the encoder keeps its previous configuration)%s");
+        return fail(M1V_E_HIP, "allocation failed (the encoder keeps its previous configuration)%s");
     }
+    // ---- commit ----
     for (int i = 0; i < sets; i++) {
         m1v_encoder::Batch &bt = e->batch[i];
         Fresh &f = fresh[i];
@@ -1812,33 +1776,17 @@ static int configure_path(m1v_encoder *e) {
             (void)hipFree(bt.seg);
             bt.seg = (uint2 *)f.seg;
         }
-        const size_t nslots = (size_t)e->max_frames * g.n_strips;
-        if (!bt.enc_done) {
-            hipError_t err = hipSuccess;
-            for (m1v_encoder::Counters &c : bt.ctr) {
-                if (err == hipSuccess) err = hipMalloc(&c.strip_ctr, nslots * 8);
-                if (err == hipSuccess) err = hipMemset(c.strip_ctr, 0, nslots * 8);
-                if (err == hipSuccess) err = hipMalloc(&c.frame_bytes, (size_t)e->max_frames * 8);
-                if (err == hipSuccess) err = hipMemset(c.frame_bytes, 0, (size_t)e->max_frames * 8);
-                if (err == hipSuccess) err = hipMalloc(&c.words, 4 * sizeof(uint32_t));
-                if (err == hipSuccess) err = hipMemset(c.words, 0, 4 * sizeof(uint32_t));
-                c.dirty_frames = 0;
-            }
+        if (f.new_fixed) {
+            bt.ctr[0] = f.ctr[0];
+            bt.ctr[1] = f.ctr[1];
             bt.turn = 0;
-            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.gather_done, hipEventDisableTiming);
-            if (err == hipSuccess) err = hipEventCreateWithFlags(&bt.enc_done, hipEventDisableTiming);
-            if (err != hipSuccess) return fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
+            bt.enc_done = f.enc_done;
+            bt.gather_done = f.gather_done;
         }
     }
-    if (plan.tiles && e->tile_order_rows != plan.tile_rows) {
-        std::vector<uint32_t> order;
-        tile_row_order_for(plan.tile_rows, order);
+    if (new_order) {
         (void)hipFree(e->d_tile_order);
-        e->d_tile_order = nullptr;
-        e->tile_order_rows = 0;
-        if (hipMalloc(&e->d_tile_order, order.size() * sizeof(uint32_t)) != hipSuccess ||
-            hipMemcpy(e->d_tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
-            return fail(M1V_E_HIP, "allocation failed%s");
+        e->d_tile_order = fresh_order;
         e->tile_order_rows = plan.tile_rows;
     }
     e->tiles = plan.tiles;
@@ -1996,6 +1944,13 @@ int m1v_strips(const m1v_encoder *e) { return e ? e->g.n_strips : 0; }
 int m1v_mb_rows(const m1v_encoder *e) { return e ? e->g.n_mbrows : 0; }
 size_t m1v_frame_bytes_in(const m1v_encoder *e) { return e ? (size_t)e->g.frame_bytes : 0; }
 
+size_t m1v_frame_bound_for(int width, int height, int mode) {
+    const int xe = mode == M1V_MODE_FULL ? (width & ~15) : 96, ye = mode == M1V_MODE_FULL ? (height & ~15) : 144;
+    if (width <= 0 || height <= 0 || xe <= 0 || ye <= 0 || xe > width || ye > height) return 0;
+    const size_t strip_bits = 38 + (size_t)(ye / 16) * (2 + 6 * kMaxBlockBits);
+    return 44 + (size_t)(xe / 16) * ((strip_bits + 7) / 8) + 4;
+}
+
 size_t m1v_frame_bound(const m1v_encoder *e) {
     if (!e) return 0;
     size_t strip_bits = 38 + (size_t)e->g.n_mbrows * (2 + 6 * kMaxBlockBits);
@@ -2004,11 +1959,14 @@ size_t m1v_frame_bound(const m1v_encoder *e) {
 
 int m1v_debug_set_lds_words(m1v_encoder *e, int words) {
     if (!e) return fail(M1V_E_ARG, "null encoder%s");
+    const int before = e->lds_words;
     e->lds_words = words > 0 ? (words < 4 ? 4 : words) : 0;
     if (!e->dense && !e->tiles) return M1V_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
-    return configure_path(e); // (a small forced image sends many runs to the overflow arena: M1V_STATUS_SCRATCH)
+    const int rc = configure_path(e); // (a small forced image sends many runs to the overflow arena: M1V_STATUS_SCRATCH)
+    if (rc != M1V_OK) e->lds_words = before;
+    return rc;
 }
 
 int m1v_reserve_scratch(m1v_encoder *e, int worst_case) {
@@ -2060,8 +2018,11 @@ int m1v_debug_set_input_mode(m1v_encoder *e, int mode) {
     if (mode != -1 && mode != 0 && mode != 2) return fail(M1V_E_ARG, "input mode must be -1 (auto), 0 (byte loads) or 2 (funnel)%s");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
+    const int before = e->forced_mode;
     e->forced_mode = mode; // an input mode is a property of the run kernels: forcing one selects them
-    return configure_path(e);
+    const int rc = configure_path(e);
+    if (rc != M1V_OK) e->forced_mode = before;
+    return rc;
 }
 
 int m1v_debug_set_dense_threads(m1v_encoder *e, int threads) {
@@ -2091,7 +2052,11 @@ int m1v_debug_set_path(m1v_encoder *e, int path) {
 
 int m1v_path_in_use(const m1v_encoder *e) { return e ? (e->tiles ? 1 : 0) : -1; }
 
-void m1v_debug_fail_alloc(int nth) { g_fail_alloc_in = nth > 0 ? nth : 0; }
+void m1v_debug_fail_alloc(int nth) {
+    // fault injection for the tests: inert unless the process was started with EC504_DEBUG_HOOKS=1
+    const char *on = getenv("EC504_DEBUG_HOOKS");
+    g_fail_alloc_in = (on && on[0] == '1' && nth > 0) ? nth : 0;
+}
 
 #if defined(M1V_STAMPS) || defined(M1V_TILE_STAMPS) || defined(M1V_ASM_STAMPS)
 // diagnostic builds only: read and clear the per-phase cycle sums
@@ -2371,6 +2336,151 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
         HIP_TRY(hipEventRecord(bt.gather_done, gs));
         bt.gather_pending = true;
     }
+    return M1V_OK;
+}
+
+// ---- overlapped delivery to the host (include/mpeg1_hip.h) ----------------------------------------------------------
+struct m1v_delivery {
+    m1v_encoder *e;
+    size_t cap;
+    int max_frames;
+    uint8_t *d_out[2], *h_out[2];
+    unsigned long long *d_meta[2], *h_meta[2];   // [0] total bytes, [1] status word (low 32 bits)
+    unsigned long long *d_sizes[2], *h_sizes[2];
+    hipStream_t side;
+    hipEvent_t encoded[2], counted[2], delivered[2];
+    bool in_flight[2];                            // delivered[b] has been recorded and not yet been waited for by an encode
+    struct {
+        const uint8_t *rgb;
+        int n, first;
+    } args[2];
+    int pending;                                  // slot whose batch is encoded (or encoding) and not yet on its way, or -1
+    unsigned step_no;
+};
+
+static int delivery_start(m1v_delivery *d, int b) { // the copy of slot b's batch, behind its encode
+    m1v_encoder *e = d->e;
+    HIP_TRY(hipStreamWaitEvent(d->side, d->encoded[b], 0));
+    HIP_TRY(hipMemcpyAsync(d->h_meta[b], d->d_meta[b], 16, hipMemcpyDeviceToHost, d->side));
+    HIP_TRY(hipEventRecord(d->counted[b], d->side));
+    HIP_TRY(hipEventSynchronize(d->counted[b])); // the step's only host wait: the next encode is already queued
+    unsigned long long total = d->h_meta[b][0];
+    uint32_t status = (uint32_t)d->h_meta[b][1];
+    if (status == M1V_STATUS_SCRATCH) { // recoverable: the worst case reserved (waits for the device), the same frames again
+        int rc = m1v_reserve_scratch(e, 1);
+        if (rc != M1V_OK) return rc;
+        rc = m1v_encode_device(e, d->args[b].rgb, d->args[b].n, d->args[b].first, d->d_out[b], d->cap, (uint64_t *)d->d_sizes[b],
+                               (uint64_t *)d->d_meta[b], reinterpret_cast<uint32_t *>(d->d_meta[b] + 1), d->side);
+        if (rc != M1V_OK) return rc;
+        if (e->pipelined) HIP_TRY(hipStreamWaitEvent(d->side, e->batch[(e->calls - 1u) & 1u].gather_done, 0));
+        HIP_TRY(hipMemcpyAsync(d->h_meta[b], d->d_meta[b], 16, hipMemcpyDeviceToHost, d->side));
+        HIP_TRY(hipStreamSynchronize(d->side));
+        total = d->h_meta[b][0];
+        status = (uint32_t)d->h_meta[b][1];
+    }
+    if (status & M1V_STATUS_UNENCODABLE) return fail(M1V_E_UNENCODABLE, "a level of 256 or more: the reference cannot code this batch%s");
+    if (status & M1V_STATUS_NOSPACE) return fail(M1V_E_NOSPACE, "the delivery's output buffers are too small for this batch%s");
+    if (status) return fail(M1V_E_SCRATCH, "the batch ran out of scratch twice%s");
+    if (total > d->cap) return fail(M1V_E_NOSPACE, "the delivery's output buffers are too small for this batch%s");
+    HIP_TRY(hipMemcpyAsync(d->h_out[b], d->d_out[b], total, hipMemcpyDeviceToHost, d->side));
+    HIP_TRY(hipMemcpyAsync(d->h_sizes[b], d->d_sizes[b], (size_t)d->args[b].n * 8, hipMemcpyDeviceToHost, d->side));
+    HIP_TRY(hipEventRecord(d->delivered[b], d->side));
+    d->in_flight[b] = true;
+    return b;
+}
+
+int m1v_delivery_create(m1v_encoder *e, size_t out_cap, m1v_delivery **out) {
+    if (!e || !out) return fail(M1V_E_ARG, "null pointer%s");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(e->device));
+    m1v_delivery *d = new m1v_delivery();
+    memset(d, 0, sizeof *d);
+    d->e = e;
+    d->max_frames = e->max_frames;
+    d->cap = out_cap ? out_cap : (size_t)e->max_frames * m1v_frame_bound(e);
+    d->pending = -1;
+    hipError_t err = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
+    for (int b = 0; b < 2; b++) {
+        if (err == hipSuccess) err = hipMalloc(&d->d_out[b], d->cap);
+        if (err == hipSuccess) err = hipMalloc(&d->d_meta[b], 16);
+        if (err == hipSuccess) err = hipMemset(d->d_meta[b], 0, 16);
+        if (err == hipSuccess) err = hipMalloc(&d->d_sizes[b], (size_t)e->max_frames * 8);
+        if (err == hipSuccess) err = hipHostMalloc(&d->h_out[b], d->cap, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipHostMalloc(&d->h_meta[b], 16, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipHostMalloc(&d->h_sizes[b], (size_t)e->max_frames * 8, hipHostMallocDefault);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d->encoded[b], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d->counted[b], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d->delivered[b], hipEventDisableTiming);
+    }
+    if (err != hipSuccess) {
+        fail(M1V_E_HIP, "allocation failed: %s", hipGetErrorString(err));
+        m1v_delivery_destroy(d);
+        return M1V_E_HIP;
+    }
+    *out = d;
+    return M1V_OK;
+}
+
+void m1v_delivery_destroy(m1v_delivery *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->e->device);
+    if (d->side) (void)hipStreamSynchronize(d->side);
+    for (int b = 0; b < 2; b++) {
+        (void)hipFree(d->d_out[b]);
+        (void)hipFree(d->d_meta[b]);
+        (void)hipFree(d->d_sizes[b]);
+        (void)hipHostFree(d->h_out[b]);
+        (void)hipHostFree(d->h_meta[b]);
+        (void)hipHostFree(d->h_sizes[b]);
+        if (d->encoded[b]) (void)hipEventDestroy(d->encoded[b]);
+        if (d->counted[b]) (void)hipEventDestroy(d->counted[b]);
+        if (d->delivered[b]) (void)hipEventDestroy(d->delivered[b]);
+    }
+    if (d->side) (void)hipStreamDestroy(d->side);
+    delete d;
+}
+
+int m1v_delivery_step(m1v_delivery *d, const uint8_t *d_rgb, int n_frames, int first_frame_index, void *stream) {
+    if (!d || !d_rgb) return fail(M1V_E_ARG, "null pointer%s");
+    if (n_frames <= 0 || n_frames > d->max_frames) return fail(M1V_E_ARG, "n_frames exceeds max_frames%s");
+    m1v_encoder *e = d->e;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(e->device));
+    const int b = (int)(d->step_no++ & 1u);
+    if (d->in_flight[b]) { // slot b's previous batch has left for the host before its buffers are written again
+        HIP_TRY(hipStreamWaitEvent(st, d->delivered[b], 0));
+        d->in_flight[b] = false;
+    }
+    const int rc = m1v_encode_device(e, d_rgb, n_frames, first_frame_index, d->d_out[b], d->cap, (uint64_t *)d->d_sizes[b],
+                                     (uint64_t *)d->d_meta[b], reinterpret_cast<uint32_t *>(d->d_meta[b] + 1), st);
+    if (rc != M1V_OK) return rc;
+    if (e->pipelined) HIP_TRY(m1v_flush(e, st) == M1V_OK ? hipSuccess : hipErrorUnknown);
+    HIP_TRY(hipEventRecord(d->encoded[b], st));
+    d->args[b].rgb = d_rgb;
+    d->args[b].n = n_frames;
+    d->args[b].first = first_frame_index;
+    const int before = d->pending;
+    d->pending = b;
+    return before >= 0 ? delivery_start(d, before) : (int)M1V_DELIVERY_NONE;
+}
+
+int m1v_delivery_flush(m1v_delivery *d) {
+    if (!d) return fail(M1V_E_ARG, "null pointer%s");
+    HIP_TRY(hipSetDevice(d->e->device));
+    const int before = d->pending;
+    d->pending = -1;
+    return before >= 0 ? delivery_start(d, before) : (int)M1V_DELIVERY_NONE;
+}
+
+uint64_t m1v_delivery_bytes(const m1v_delivery *d, int slot) { return d && slot >= 0 && slot <= 1 ? d->h_meta[slot][0] : 0; }
+
+int m1v_delivery_wait(m1v_delivery *d, int slot, const uint8_t **host, uint64_t *bytes, const uint64_t **frame_sizes) {
+    if (!d || slot < 0 || slot > 1) return fail(M1V_E_ARG, "bad slot%s");
+    HIP_TRY(hipSetDevice(d->e->device));
+    HIP_TRY(hipEventSynchronize(d->delivered[slot]));
+    if (host) *host = d->h_out[slot];
+    if (bytes) *bytes = d->h_meta[slot][0];
+    if (frame_sizes) *frame_sizes = (const uint64_t *)d->h_sizes[slot];
     return M1V_OK;
 }
 

@@ -117,10 +117,10 @@ __device__ __forceinline__ int columns_to_stage(const RowStore<KEEP> &rows, cons
     return dc;
 }
 
-// Row-pass outputs stay unpacked (RowStore<8>: 64 registers, 96 VGPRs = 5 waves per SIMD).  Packing them as f16 pairs
-// (RowStore<0>: 66 VGPRs, 6 waves per SIMD) wins 2 % while the launches come in bursts of a few and the chip boosts, and loses
-// 0.5-2.5 % in a sustained run, where the package sits at its 1400 W limit and the 96 extra conversions per block cost more
-// than the sixth wave hides (tools/sustained.py, profiles/r03_ab_history.txt).
+// Row-pass outputs stay unpacked (RowStore<8>: 64 registers, 96 VGPRs = 5 waves per SIMD).  Packing all of them as f16 pairs
+// (66 VGPRs, 6 waves per SIMD) won 2 % while the launches came in bursts of a few and the chip boosted, and lost 0.5-2.5 % in a
+// sustained run, where the package sits at its 1400 W limit and the 96 extra conversions per block cost more than the sixth
+// wave hides (tools/sustained.py, profiles/r03_ab_history.txt); that form was removed in round 4.
 #ifndef M1V_TILE_KEEP
 #define M1V_TILE_KEEP 8
 #endif
@@ -339,13 +339,9 @@ void k_encode_tiles(TileArgs a) {
     BlockBits bb = {0, 0};
     dc_header(dc, blk < 4, blk, vlc, hdr, hlen);
     const unsigned long long emit = emit_set(nz);
-#if defined(M1V_TILE_PASS1_PAIRS)
-    block_bits_pass1_pairs<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
-#else
-    // one coefficient per trip: two per trip (half the dependent LDS round trips) is no faster in bursts and 1 % slower in a
-    // sustained run — the lanes with a single coefficient left do the second one's work for nothing (r03_ab_history.txt)
+    // one coefficient per trip: two per trip (half the dependent LDS round trips) measured no faster in bursts and 1 % slower in
+    // a sustained run — the lanes with a single coefficient left do the second one's work for nothing (r03_ab_history.txt)
     block_bits_pass1<STAGE8>(hdr, hlen, dc != 0, emit, vlc, fetch, bb.acc, bb.tot, bad);
-#endif
     if (!valid) {
         bb.tot = 0;
         bad = 0;

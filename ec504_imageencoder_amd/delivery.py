@@ -1,84 +1,100 @@
 """Delivery of the frame records to the HOST, overlapped with the next batch's encode (north_star: the path ends in "a
 contiguous host bitstream"; the reference writes it with bitvector_fwrite, include/encoder.h:445).
 
-`HostDelivery` is the single-GPU analogue of sharding.StepPipeline: batch k+1 encodes on the main stream while batch k's
-records travel device-to-host on a side stream into one of two pinned buffers.  The copy needs the batch's byte count on
-the host, so once per step the host waits for ONE event — "the 16 bytes (total, status) of batch k have reached pinned
-memory" — and at that moment the main stream already holds the encode of batch k+1.  Nothing is allocated inside the loop.
-A batch that ran out of overflow scratch (M1V_STATUS_SCRATCH, recoverable) is encoded again with the worst case reserved, as
-sharding.StepPipeline does; a batch with any other status bit is not delivered: step() raises.
+The overlap lives in the C library (m1v_delivery_* in include/mpeg1_hip.h, csrc/m1v_kernels.hip): two device output buffers
+and two pinned host buffers owned by the delivery object, the device-to-host copy of batch k on an internal stream under the
+encode of batch k+1, one host wait per step for the 16 bytes (total, status) of the batch that is about to travel.  A batch
+that ran out of overflow scratch (M1V_STATUS_SCRATCH) is encoded again with the worst case reserved; any other status bit
+fails the step.  `HostDelivery` is the ctypes mirror of that object (a `main.c`-style C caller uses the same five functions).
 """
+import ctypes as C
+
 from . import _ffi
+from .encoder import EncoderError, _ptr, _stream
+
+
+class _Arrival:
+    """What `HostDelivery.delivered[slot]` holds: synchronize() blocks until that slot's copy has reached the host."""
+
+    def __init__(self, hd, slot):
+        self.hd, self.slot = hd, slot
+
+    def synchronize(self):
+        self.hd._wait(self.slot)
 
 
 class HostDelivery:
     def __init__(self, enc, n_frames, capacity=None, n_buffers=2):
-        import torch
-        self.torch, self.enc = torch, enc
-        dev = torch.device("cuda", enc.device)
+        assert n_buffers == 2, "the library double-buffers"
+        self.enc, self.n_frames = enc, n_frames
         cap = int(capacity if capacity is not None else enc.default_out_capacity(n_frames))
-        self.outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n_buffers)]
-        self.sizes = [torch.empty(max(n_frames, 1), dtype=torch.int64, device=dev) for _ in range(n_buffers)]
-        self.metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(n_buffers)]
-        self.host = [torch.empty(cap, dtype=torch.uint8, pin_memory=True) for _ in range(n_buffers)]
-        self.host_meta = [torch.zeros(2, dtype=torch.int64, pin_memory=True) for _ in range(n_buffers)]
-        self.side = torch.cuda.Stream(device=dev)
-        self.encoded = [torch.cuda.Event() for _ in range(n_buffers)]
-        self.counted = [torch.cuda.Event() for _ in range(n_buffers)]
-        self.delivered = [None] * n_buffers
-        self.args = [None] * n_buffers   # what buffer b was encoded from (for the scratch retry)
-        self.pending, self.step_no = [], 0
-        self.last = None            # (buffer index, total bytes) of the newest delivered batch
+        self._h = C.c_void_p(0)
+        rc = _ffi.lib().m1v_delivery_create(enc._h, cap, C.byref(self._h))
+        if rc != _ffi.OK:
+            self._h = C.c_void_p(0)
+            raise EncoderError(rc, "m1v_delivery_create")
+        self.capacity = cap
+        self.delivered = [None, None]
+        self.last = None            # (slot, total bytes) of the newest batch on its way / delivered
         self.bytes_delivered = 0
+        self._keep = [None, None]   # the input of the batch in each slot: must outlive the start of its copy
+        self._step = 0
 
-    def _deliver(self, b):
-        torch = self.torch
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.encoded[b])
-            self.host_meta[b].copy_(self.metas[b], non_blocking=True)
-            self.counted[b].record(self.side)
-            self.counted[b].synchronize()       # the step's only host wait; the next encode is already queued
-            total, status = int(self.host_meta[b][0]), int(self.host_meta[b][1]) & 0xFFFFFFFF
-            if status == _ffi.STATUS_SCRATCH and self.args[b] is not None:
-                # recoverable: reserve the worst case (waits for the device), encode the same frames again on this stream
-                rgb, first = self.args[b]
-                self.enc.reserve_scratch(True)
-                self.enc.encode(rgb, first, out=self.outs[b], sizes=self.sizes[b], meta=self.metas[b])
-                self.host_meta[b].copy_(self.metas[b], non_blocking=True)
-                self.side.synchronize()
-                total, status = int(self.host_meta[b][0]), int(self.host_meta[b][1]) & 0xFFFFFFFF
-            if status:
-                raise RuntimeError(f"encode status {status:#x}: the batch's output is undefined and is not delivered")
-            if total > self.host[b].numel():
-                raise RuntimeError("pinned buffer too small")
-            self.host[b][:total].copy_(self.outs[b][:total], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.delivered[b] = ev
-        self.last = (b, total)
+    def close(self):
+        if self._h:
+            _ffi.lib().m1v_delivery_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _started(self, slot):
+        if slot == _ffi.DELIVERY_NONE:
+            return
+        if slot < 0:
+            raise EncoderError(slot, "m1v_delivery_step")
+        self.delivered[slot] = _Arrival(self, slot)
+        total = int(_ffi.lib().m1v_delivery_bytes(self._h, slot))   # on the host since the step's wait
+        self.last = (slot, total)
         self.bytes_delivered += total
 
+    def _wait(self, slot):
+        host, nbytes, sizes = C.c_void_p(0), C.c_uint64(0), C.c_void_p(0)
+        rc = _ffi.lib().m1v_delivery_wait(self._h, slot, C.byref(host), C.byref(nbytes), C.byref(sizes))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_delivery_wait")
+        return host.value, int(nbytes.value), sizes.value
+
     def step(self, rgb, first_frame_index=0):
-        """Encode `rgb` (device-resident) into buffer b; deliver the previous batch behind it."""
-        b = self.step_no % len(self.outs)
-        self.step_no += 1
-        if self.delivered[b] is not None:
-            self.torch.cuda.current_stream().wait_event(self.delivered[b])   # buffer b has left for the host: free again
-        self.enc.encode(rgb, first_frame_index, out=self.outs[b], sizes=self.sizes[b], meta=self.metas[b])
-        self.encoded[b].record()
-        self.args[b] = (rgb, first_frame_index)
-        self.pending.append(b)
-        if len(self.pending) > 1:
-            self._deliver(self.pending.pop(0))
+        """Encode `rgb` (device-resident) on the current stream; the batch before it starts travelling behind it."""
+        slot_in = self._step & 1
+        self._step += 1
+        self._keep[slot_in] = rgb
+        n = int(rgb.shape[0])
+        self._started(_ffi.lib().m1v_delivery_step(self._h, _ptr(rgb), n, int(first_frame_index), _stream()))
 
     def fence(self):
-        while self.pending:
-            self._deliver(self.pending.pop(0))
-        self.torch.cuda.synchronize()
+        import torch
+        self._started(_ffi.lib().m1v_delivery_flush(self._h))
+        if self.last is not None:
+            self._wait(self.last[0])
+        torch.cuda.synchronize()
 
     def result(self):
-        """After fence(): the newest delivered batch as a pinned uint8 tensor (a view of one of the two buffers)."""
+        """The newest delivered batch as a uint8 tensor over the library's pinned buffer (waits for its arrival)."""
         if self.last is None:
             return None
-        b, total = self.last
-        return self.host[b][:total]
+        import numpy as np
+        import torch
+        host, total, _ = self._wait(self.last[0])
+        buf = (C.c_uint8 * total).from_address(host)
+        return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+    def frame_sizes(self, n):
+        """Byte counts of the newest delivered batch's `n` frame records."""
+        import numpy as np
+        _, _, sizes = self._wait(self.last[0])
+        return np.ctypeslib.as_array((C.c_uint64 * n).from_address(sizes)).copy()

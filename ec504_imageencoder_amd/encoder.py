@@ -244,7 +244,9 @@ class Mpeg1Encoder:
         return "tiles" if _ffi.lib().m1v_path_in_use(self._h) == 1 else "runs"
 
     def debug_set_lds_words(self, words):
-        _ffi.lib().m1v_debug_set_lds_words(self._h, int(words))
+        rc = _ffi.lib().m1v_debug_set_lds_words(self._h, int(words))
+        if rc != _ffi.OK:
+            raise EncoderError(rc, "m1v_debug_set_lds_words")
 
     def debug_set_dense_threads(self, threads):
         rc = _ffi.lib().m1v_debug_set_dense_threads(self._h, int(threads))

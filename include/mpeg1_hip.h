@@ -90,6 +90,7 @@ size_t m1v_scratch_bytes(const m1v_encoder *enc); /* device bytes currently held
 int m1v_strips(const m1v_encoder *enc);          /* x_extent / 16 */
 int m1v_mb_rows(const m1v_encoder *enc);         /* y_extent / 16 */
 size_t m1v_frame_bound(const m1v_encoder *enc);  /* worst-case bytes of one frame record */
+size_t m1v_frame_bound_for(int width, int height, int mode); /* the same without an encoder (0: geometry not encodable) */
 size_t m1v_frame_bytes_in(const m1v_encoder *enc); /* width*height*channels */
 
 /* PACK(12)+SYS(15), written once per file.  Returns 27. */
@@ -118,6 +119,31 @@ int m1v_set_pipelined(m1v_encoder *enc, int enable);
  * be driven from ONE stream; calls on another stream are still ordered behind the gather that last used their set
  * of internal buffers. */
 int m1v_flush(m1v_encoder *enc, void *stream);
+
+/* Overlapped delivery of the frame records to the HOST (the path ends in a host bitstream: the reference writes it with
+ * bitvector_fwrite, include/encoder.h:445).  Input resident in device memory; the device-to-host copy of batch k runs on an
+ * internal stream under the encode of batch k+1, through two device output buffers and two pinned host buffers owned by the
+ * delivery object.  Nothing is allocated inside the loop; one host wait per step (for 16 bytes: the batch's byte count and
+ * status word).  A batch that ran out of overflow scratch is encoded again with the worst case reserved; any other status
+ * bit fails the step (nothing of an undefined batch is delivered).
+ *
+ *   m1v_delivery_create(enc, out_cap, &d)      out_cap = capacity of each output buffer in bytes (0: max_frames x frame bound)
+ *   slot = m1v_delivery_step(d, d_rgb, n, first_index, stream)
+ *                                              queues the encode of this batch on `stream`, then starts the copy of the batch
+ *                                              BEFORE it; returns that batch's slot (0 or 1), M1V_DELIVERY_NONE on the first
+ *                                              call, or a negative M1V_E_*.  d_rgb must stay valid until the batch's copy has started.
+ *   slot = m1v_delivery_flush(d)               starts the copy of the last batch (M1V_DELIVERY_NONE if none is pending)
+ *   m1v_delivery_wait(d, slot, &host, &bytes, &frame_sizes)
+ *                                              blocks until that slot's copy has arrived; host / frame_sizes point into the
+ *                                              slot's pinned buffers, valid until the second step after the one that returned it */
+typedef struct m1v_delivery m1v_delivery;
+enum { M1V_DELIVERY_NONE = 2 };
+int m1v_delivery_create(m1v_encoder *enc, size_t out_cap, m1v_delivery **out);
+void m1v_delivery_destroy(m1v_delivery *d);
+int m1v_delivery_step(m1v_delivery *d, const uint8_t *d_rgb, int n_frames, int first_frame_index, void *stream);
+int m1v_delivery_flush(m1v_delivery *d);
+int m1v_delivery_wait(m1v_delivery *d, int slot, const uint8_t **host, uint64_t *bytes, const uint64_t **frame_sizes);
+uint64_t m1v_delivery_bytes(const m1v_delivery *d, int slot); /* bytes of the batch in `slot`: known once its copy has been started */
 
 /* Starts the GPU runtime for `device` (context, code objects) so that a later m1v_create() does not pay for it.
  * Optional; meant to be called from another thread while the caller is still busy with host work. */
@@ -176,7 +202,7 @@ int m1v_debug_set_path(m1v_encoder *enc, int path);
 int m1v_path_in_use(const m1v_encoder *enc); /* 1 = tiles, 0 = runs */
 /* Test hook: the nth device allocation made from now on by a reconfiguration (m1v_reserve_scratch, m1v_set_pipelined,
  * the m1v_debug_set_* hooks) fails as if the device were out of memory; 0 = off.  A failed reconfiguration returns
- * M1V_E_HIP and leaves the encoder exactly as it was. */
+ * M1V_E_HIP and leaves the encoder exactly as it was.  Inert unless the process runs with EC504_DEBUG_HOOKS=1. */
 void m1v_debug_fail_alloc(int nth);
 /* Test hook: force how the RUN kernel loads its pixels (forcing a mode selects the run path): -1 = automatic (by width,
  * channel count and pointer alignment), 0 = byte loads (valid everywhere), 2 = 28-byte loads + funnel shift (3 channels,

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+os.environ.setdefault("EC504_DEBUG_HOOKS", "1")   # arms m1v_debug_fail_alloc (fault injection; inert in a normal process)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs oracle/_ref built from /root/reference (authoring container)")

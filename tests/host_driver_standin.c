@@ -41,6 +41,7 @@ int m1v_create(m1v_encoder **out, int device, int w, int h, int channels, int qf
 void m1v_destroy(m1v_encoder *e) { free(e); }
 size_t m1v_frame_bytes_in(const m1v_encoder *e) { return (size_t)e->W * e->H * e->C; }
 size_t m1v_frame_bound(const m1v_encoder *e) { return orc_frame_bound(e->W, e->H, e->mode); }
+size_t m1v_frame_bound_for(int width, int height, int mode) { return orc_frame_bound(width, height, mode); }
 void *m1v_alloc_host(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void m1v_free_host(void *p) { free(p); }
 

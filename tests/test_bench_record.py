@@ -54,3 +54,15 @@ def test_saved_bench_lines_carry_the_contract_fields():
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
         assert r["traffic"] and r["valu"] and r["launches_timed"] == d["steps"]
         assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_launches_its_own_ranks_command():
+    """`python bench.py --gpus N` without WORLD_SIZE starts torch.distributed.run as a child (never exec, never touches the GPU
+    in the parent): one rank per GPU, rendezvous on 127.0.0.1, the same arguments."""
+    b = _bench()
+    cmd = b.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29555, script="/x/bench.py")
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-7:] == ["/x/bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src

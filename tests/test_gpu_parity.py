@@ -5,6 +5,8 @@ import functools
 import hashlib
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -164,7 +166,73 @@ def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path)
     enc.reserve_scratch(True)
     assert enc.scratch_bytes() > before
     assert enc.encode_to_bytes(rgb, 7)[0] == want
+    # a switch of the encode kernel allocates the other path's scratch, segment table, run metadata / tile order: whichever of
+    # them fails, the encoder stays on the path it was on — and a forced LDS image that cannot be set up leaves the old one
+    other = "runs" if path == "tiles" else "tiles"
+    for nth in (1, 2, 3):
+        before = enc.scratch_bytes()
+        _ffi.lib().m1v_debug_fail_alloc(nth)
+        try:
+            enc.debug_set_path(other)
+            failed = False
+        except EncoderError as err:
+            failed = True
+            assert err.code == _ffi.E_HIP
+        _ffi.lib().m1v_debug_fail_alloc(0)
+        if failed:
+            assert enc.path == path and enc.scratch_bytes() == before
+            assert enc.encode_to_bytes(rgb, 7)[0] == want
+        else:                       # fewer than nth allocations were needed: the switch went through
+            assert enc.path == other and enc.encode_to_bytes(rgb, 7)[0] == want
+            enc.debug_set_path(path)
+    _ffi.lib().m1v_debug_fail_alloc(1)
+    with pytest.raises(EncoderError):
+        enc.debug_set_lds_words(8)
+    _ffi.lib().m1v_debug_fail_alloc(0)
+    assert enc.encode_to_bytes(rgb, 7)[0] == want
     enc.close()
+
+
+def test_host_delivery_retries_a_batch_that_ran_out_of_scratch(torch_cuda, orc):
+    """A forced tiny LDS image sends every unit to the overflow arena, which the default reservation cannot hold: the batch
+    reports M1V_STATUS_SCRATCH.  HostDelivery (and StepPipeline, world 1, below) reserve the worst case and encode the same
+    frames again behind the batch that is already queued; what is delivered is the oracle's stream."""
+    from ec504_imageencoder_amd.delivery import HostDelivery
+    W, H, n = 1280, 720, 24
+    enc = _enc(W, H, max_frames=n)
+    enc.debug_set_lds_words(8)
+    hd = HostDelivery(enc, n)
+    batches = [enc.synth(n, seed=90 + k) for k in range(3)]
+    wants = [orc.encode_frames(b.cpu().numpy(), n, W, H, 10 * k, 12, orc.MODE_FULL)[0] for k, b in enumerate(batches)]
+    got = []
+    for k, b in enumerate(batches):
+        hd.step(b, 10 * k)
+        if hd.last is not None and len(got) < k:
+            hd.delivered[hd.last[0]].synchronize()
+            got.append(bytes(hd.result().numpy()))
+    hd.fence()
+    got.append(bytes(hd.result().numpy()))
+    assert got == wants
+    enc.close()
+
+
+def test_bench_starts_its_own_ranks(torch_cuda):
+    """`python bench.py --gpus 2` as the driver runs it (no torchrun around it): bench.py starts torch.distributed.run as a child
+    and prints ONE JSON line with n_gpus 2.  Rehearsal on this one-GPU box: gloo, both ranks on cuda:0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--frames", "8", "--width", "352", "--height", "288", "--settle-ms", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_frames"] == 16 and d["value"] > 0
+    assert "step_frac" in d["roofline"]
 
 
 def test_host_delivery_overlapped_with_the_next_encode(torch_cuda, orc):
