@@ -20,7 +20,11 @@
  *                                     encoder_release_cache() and process exit free it)
  *   EC504_BATCH=<n>                   frames per device batch                  (default 64)
  *   EC504_HOST_THREADS=<n>            decode / staging / .bit-writer threads   (default: the CPUs this process may run
- *                                     on, <= 512; 1 = everything on the calling thread, as the reference)
+ *                                     on or 1.25 x its cgroup CPU quota, whichever is smaller, at most 64; an explicit
+ *                                     value up to 512 is taken as given; 1 = everything on the calling thread, as the
+ *                                     reference)
+ *   EC504_EXTRA_SLOTS=<n>             pinned staging slots beyond one per encoder (default 1; each holds one chunk of
+ *                                     pixels and, with .bit files, one chunk of planes)
  */
 #define _GNU_SOURCE
 #define _DEFAULT_SOURCE
@@ -100,6 +104,22 @@ static int pool_take(Pool *p, Group **g, int *i) {
     return 1;
 }
 
+/* with mu held: the next index of group g itself, if g still has unclaimed tasks in the queue */
+static int pool_take_from(Pool *p, Group *g, int *i) {
+    Group *prev = NULL;
+    for (Group *h = p->head; h; prev = h, h = h->link) {
+        if (h != g) continue;
+        *i = h->next++;
+        if (h->next >= h->n) {
+            if (prev) prev->link = h->link;
+            else p->head = h->link;
+            if (p->tail == h) p->tail = prev;
+        }
+        return 1;
+    }
+    return 0;
+}
+
 static void pool_finish(Pool *p, Group *g) { /* with mu held */
     if (++g->done == g->n) pthread_cond_broadcast(&p->idle);
 }
@@ -169,14 +189,16 @@ static void group_start_front(Pool *p, Group *g, void (*fn)(void *, int), void *
 }
 
 /* Returns when every task of g has run — or, with a flag, as soon as *flag is set (under p->mu, with a
- * broadcast on p->idle); the caller runs queued tasks (of any group) meanwhile. */
+ * broadcast on p->idle).  Meanwhile the caller runs tasks of g itself; tasks of OTHER groups only when the pool has no
+ * thread of its own (EC504_HOST_THREADS=1: the serial program) — a caller that picks up a 12-ms decode while it waits for a
+ * 1-ms staging copy paces the whole pipeline at one decode per chunk (measured: 14 ms per chunk whatever the thread count). */
 static void group_wait_or(Pool *p, Group *g, const int *flag) {
     if (g->n <= 0) return;
     pthread_mutex_lock(&p->mu);
     while (g->done < g->n && !(flag && *flag)) {
-        Group *h;
+        Group *h = g;
         int i;
-        if (pool_take(p, &h, &i)) {
+        if (pool_take_from(p, g, &i) || (p->n_threads == 0 && pool_take(p, &h, &i))) {
             pthread_mutex_unlock(&p->mu);
             h->fn(h->ctx, i);
             pthread_mutex_lock(&p->mu);
@@ -203,6 +225,21 @@ static void pool_close(Pool *p) {
 }
 
 /* ---- the three kinds of host task ------------------------------------------------------------- */
+static int g_task_timing = 0;              /* EC504_TIMING: sum the tasks' own durations (microseconds) and count them */
+static long long g_task_us[4], g_task_n[4]; /* decode, stage, .bit write, GPU */
+static double now_s(void);
+#define TASK_TIMED(kind, stmt)                                                     \
+    do {                                                                           \
+        if (!g_task_timing) {                                                      \
+            stmt;                                                                  \
+        } else {                                                                   \
+            const double t0_ = now_s();                                            \
+            stmt;                                                                  \
+            __atomic_fetch_add(&g_task_us[kind], (long long)((now_s() - t0_) * 1e6), __ATOMIC_RELAXED); \
+            __atomic_fetch_add(&g_task_n[kind], 1, __ATOMIC_RELAXED);              \
+        }                                                                          \
+    } while (0)
+
 typedef struct {
     char **path; /* the chunk's first file */
     Image *img;  /* img[i].data == NULL afterwards: the loader refused path[i] */
@@ -212,7 +249,7 @@ static void decode_task(void *ctx, int i) { /* encoder.h:162 */
     DecodeJob *j = (DecodeJob *)ctx;
     Image *im = &j->img[i];
     if (im->data) return; /* the head file: decoded before the pipeline started */
-    im->data = g_load(j->path[i], &im->width, &im->height, &im->channels, 0);
+    TASK_TIMED(0, im->data = g_load(j->path[i], &im->width, &im->height, &im->channels, 0));
 }
 
 static void warm_task(void *ctx, int i) { /* start the GPU runtime (device i of the list) while the first files decode */
@@ -237,8 +274,10 @@ static void alloc_task(void *ctx, int i) { /* one pinned buffer (page-locking ~1
 
 static void stage_task(void *ctx, int i) {
     StageJob *j = (StageJob *)ctx;
-    memcpy(j->dst + j->frame_in * (size_t)i, j->img[i].data, j->frame_in);
-    if (g_free) g_free(j->img[i].data); /* the decoded copy is not needed again */
+    TASK_TIMED(1, {
+        memcpy(j->dst + j->frame_in * (size_t)i, j->img[i].data, j->frame_in);
+        if (g_free) g_free(j->img[i].data); /* the decoded copy is not needed again */
+    });
     j->img[i].data = NULL;
 }
 
@@ -249,8 +288,9 @@ typedef struct {
 } BitJob;
 
 /* image_processing.c:753-787: int32 W, int32 H, then the Y, Cb, Cr planes (full resolution). */
-static void bit_task(void *ctx, int i) {
-    BitJob *j = (BitJob *)ctx;
+static void bit_write(const BitJob *j, int i);
+static void bit_task(void *ctx, int i) { TASK_TIMED(2, bit_write((const BitJob *)ctx, i)); }
+static void bit_write(const BitJob *j, int i) {
     char path[256];
     snprintf(path, sizeof path, "%s/image_%d.bit", j->folder, j->first_k + i);
     FILE *f = fopen(path, "wb");
@@ -277,7 +317,7 @@ static void remove_bit_file(const char *folder, int k) {
  * frame index travels with it), or twice on the same GPU, where the upload of one chunk overlaps the kernels and the
  * downloads of the other.  The caller retires chunks in order and appends their frame records to the video: the file is
  * the gather. */
-enum { MAX_LANES = 16 };
+enum { MAX_LANES = 16, MAX_SLOTS = MAX_LANES + 8 };
 
 typedef struct {
     m1v_encoder *enc;
@@ -295,7 +335,7 @@ typedef struct {
 static void gpu_task(void *ctx, int i) {
     Lane *l = (Lane *)ctx;
     (void)i;
-    l->total = m1v_encode_planes_host(l->enc, l->in, l->n, l->first, l->out, l->out_cap, l->sizes, l->planes);
+    TASK_TIMED(3, l->total = m1v_encode_planes_host(l->enc, l->in, l->n, l->first, l->out, l->out_cap, l->sizes, l->planes));
     if (l->total < 0) snprintf(l->err, sizeof l->err, "%s", m1v_last_error());
 }
 
@@ -305,7 +345,7 @@ typedef struct {
     int valid;
     int devices[MAX_LANES], n_lanes, W, H, C, qf, region, batch, write_bit, n_slots;
     Lane lane[MAX_LANES];
-    uint8_t *batch_in[MAX_LANES + 1], *planes[MAX_LANES + 1];
+    uint8_t *batch_in[MAX_SLOTS], *planes[MAX_SLOTS];
 } GpuContext;
 
 static GpuContext g_cache;
@@ -365,12 +405,40 @@ static double now_s(void) {
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+/* CPUs' worth of time the process may use per period: the cgroup's quota (v2 cpu.max, v1 cpu.cfs_quota_us), or 0 = unlimited */
+static int cgroup_cpu_quota(void) {
+    long quota = -1, period = 100000;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32];
+        if (fscanf(f, "%31s %ld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL) {
+        if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) != NULL) {
+            if (fscanf(f, "%ld", &period) != 1) period = 100000;
+            fclose(f);
+        }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)((quota + period - 1) / period);
+}
+
+/* Default: what the process can actually run at once — the CPUs it may be scheduled on, or its cgroup's CPU quota when that
+ * is smaller (+25 %: some tasks wait for the GPU or the file system) — and at most 64.  Measured on the 256-CPU host with a
+ * 16-CPU quota (profiles/r04_cli_phase_times.txt): a decode takes 10.5 ms alone, 11 ms among 16 threads, 40 ms among 64 (the
+ * quota throttles them); 128 or 256 threads also slow the GPU runtime's start-up.  EC504_HOST_THREADS / encoder_set_host_threads
+ * are taken as given (up to 512). */
 static int host_threads(void) {
     int n = env_int("EC504_HOST_THREADS", g_threads);
-    if (n <= 0) { /* the CPUs this process may run on (a container's share), not the machine's */
+    if (n <= 0) {
         cpu_set_t set;
         long cpus = sched_getaffinity(0, sizeof set, &set) == 0 ? (long)CPU_COUNT(&set) : sysconf(_SC_NPROCESSORS_ONLN);
+        const int quota = cgroup_cpu_quota();
         n = cpus < 1 ? 1 : (int)cpus;
+        if (quota > 0 && quota + quota / 4 < n) n = quota + quota / 4;
+        if (n > 64) n = 64;
     }
     return n > 512 ? 512 : n;
 }
@@ -446,16 +514,21 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     enum { RING = 48 }; /* decode groups in flight, at most RING-1 chunks ahead of the GPU */
     int rc = -1, mismatch = 0;
     const int timing = env_int("EC504_TIMING", 0); /* phase times on stderr */
+    g_task_timing = timing;
+    memset(g_task_us, 0, sizeof g_task_us);
+    memset(g_task_n, 0, sizeof g_task_n);
     double t_phase[5] = {now_s(), 0, 0, 0, 0}, t_created = 0;
+    double t_wait[5] = {0, 0, 0, 0, 0}, t_mark; /* the caller's waits inside the chunk loop: staged, decoded, .bit writers, GPU, fwrite */
+#define TIMED(k, stmt) do { t_mark = now_s(); stmt; t_wait[k] += now_s() - t_mark; } while (0)
     Pool pool;
     pool_open(&pool, host_threads());
     ImageList imgs = {NULL, 0, 0};
     GpuContext cx;
     memset(&cx, 0, sizeof cx);
-    Group staged[MAX_LANES + 1], written[MAX_LANES + 1], on_gpu[MAX_LANES], decoded[RING], warm;
+    Group staged[MAX_SLOTS], written[MAX_SLOTS], on_gpu[MAX_LANES], decoded[RING], warm;
     DecodeJob dj[RING];
-    StageJob sj[MAX_LANES + 1];
-    BitJob bj[MAX_LANES + 1];
+    StageJob sj[MAX_SLOTS];
+    BitJob bj[MAX_SLOTS];
     memset(staged, 0, sizeof staged);
     memset(written, 0, sizeof written);
     memset(on_gpu, 0, sizeof on_gpu);
@@ -522,7 +595,11 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     }
     const int write_bit = env_int("EC504_WRITE_BIT", 1);
     cx.W = W, cx.H = H, cx.C = C, cx.qf = quality_factor, cx.region = region, cx.batch = batch, cx.write_bit = write_bit;
-    cx.n_slots = n_chunks > N ? N + 1 : N; /* chunks on the lanes + the one being staged */
+    {   /* chunks on the lanes + those being staged or still feeding their .bit writers (EC504_EXTRA_SLOTS, default 1) */
+        int extra = env_int("EC504_EXTRA_SLOTS", 1);
+        extra = extra < 1 ? 1 : (extra > MAX_SLOTS - N ? MAX_SLOTS - N : extra);
+        cx.n_slots = n_chunks > N ? (N + extra > n_chunks ? n_chunks : N + extra) : N;
+    }
     chunk_frames = (int *)calloc((size_t)n_chunks + 1, sizeof(int));
     chunk_first = (int *)calloc((size_t)n_chunks + 1, sizeof(int));
     int alloc_ok = chunk_frames && chunk_first;
@@ -539,7 +616,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
         /* pinned staging (copies to and from the GPU then run at the PCIe rate), page-locked by the pool IN FRONT of the
          * queued decodes while this thread creates the encoders.  A lane's output buffer starts at 1/16 of the worst case
          * (white noise needs about 1/46 of it, pictures built to be expensive about 1/11) and grows on demand (see below). */
-        AllocItem items[3 * MAX_LANES + 2];
+        AllocItem items[MAX_LANES + 2 * MAX_SLOTS];
         int n_items = 0;
         Group allocs;
         memset(&allocs, 0, sizeof allocs);
@@ -596,7 +673,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
     /* Iteration c: chunk c+1 is joined from its decode and handed to the pool for staging; chunk c (staged) goes to its
      * lane; chunk c-N+1 is retired: its records are appended to the video, its .bit files handed to the pool. */
     for (int c = -1; c < n_chunks + N - 1; c++) {
-        if (c >= 0 && c < n_chunks) group_wait(&pool, &staged[c % S]);
+        if (c >= 0 && c < n_chunks) TIMED(0, group_wait(&pool, &staged[c % S]));
         if (c >= 0 && next_decode < n_chunks) { /* keep `look` chunks of decoding ahead of the GPU */
             const int r = next_decode % RING; /* ring entry of a chunk <= c-1, joined at least one pass ago */
             dj[r] = (DecodeJob){paths + CHUNK_FIRST(next_decode), imgs.v + CHUNK_FIRST(next_decode)};
@@ -607,7 +684,7 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
             const int first = CHUNK_FIRST(c + 1), files = CHUNK_FILES(c + 1), slot = (c + 1) % S;
             Image *v = imgs.v + first;
             int n_next = 0;
-            group_wait(&pool, &decoded[(c + 1) % RING]);
+            TIMED(1, group_wait(&pool, &decoded[(c + 1) % RING]));
             for (int i = 0; i < files; i++) {
                 if (!v[i].data) {
                     printf("Error loading image %s\n", paths[first + i]);
@@ -627,9 +704,9 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
             chunk_frames[c + 1] = n_next;
             chunk_first[c + 1] = c >= 0 ? chunk_first[c] + chunk_frames[c] : 0;
             /* the slot's previous chunk (c+1-S) left its lane at least one pass ago; its .bit files may still be on their way */
-            group_wait(&pool, &written[slot]);
+            TIMED(2, group_wait(&pool, &written[slot]));
             sj[slot] = (StageJob){v, cx.batch_in[slot], frame_in};
-            group_start(&pool, &staged[slot], stage_task, &sj[slot], n_next);
+            group_start_front(&pool, &staged[slot], stage_task, &sj[slot], n_next); /* in front of the decodes that run ahead */
         }
         if (c >= 0 && c < n_chunks && chunk_frames[c] > 0) { /* chunk c onto its lane (free: its previous chunk, c-N, was retired one pass ago) */
             Lane *l = &cx.lane[c % N];
@@ -638,13 +715,13 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
             l->n = chunk_frames[c];
             l->first = chunk_first[c];
             l->total = M1V_E_HIP;
-            group_start(&pool, &on_gpu[c % N], gpu_task, l, 1);
+            group_start_front(&pool, &on_gpu[c % N], gpu_task, l, 1);
         }
         const int retire = c - N + 1;
         if (retire >= 0 && retire < n_chunks && chunk_frames[retire] > 0) {
             Lane *l = &cx.lane[retire % N];
             const int slot = retire % S, n_cur = chunk_frames[retire];
-            group_wait(&pool, &on_gpu[retire % N]);
+            TIMED(3, group_wait(&pool, &on_gpu[retire % N]));
             if (l->total == M1V_E_NOSPACE && l->out_cap < bound * (size_t)batch) { /* rare: grow to the worst case, redo */
                 m1v_free_host(l->out);
                 l->out_cap = bound * (size_t)batch;
@@ -656,10 +733,10 @@ int mpeg_encode_procedure_region(const char *images_folder, const char *bitstrea
                 printf("Error: GPU encode failed: %s\n", l->err);
                 goto done;
             }
-            fwrite(l->out, 1, (size_t)l->total, fp);
+            TIMED(4, fwrite(l->out, 1, (size_t)l->total, fp));
             if (write_bit) { /* encoder.h:461-465, written behind the following chunks */
                 bj[slot] = (BitJob){bitstream_folder, cx.planes[slot], frames_done + 1, W, H};
-                group_start(&pool, &written[slot], bit_task, &bj[slot], n_cur);
+                group_start_front(&pool, &written[slot], bit_task, &bj[slot], n_cur);
             }
             frames_done += n_cur;
         }
@@ -672,7 +749,7 @@ done:
     group_wait(&pool, &warm); /* nothing may still reference what is freed below */
     for (int r = 0; r < RING; r++) group_wait(&pool, &decoded[r]);
     for (int l = 0; l < MAX_LANES; l++) group_wait(&pool, &on_gpu[l]);
-    for (int s = 0; s <= MAX_LANES; s++) {
+    for (int s = 0; s < MAX_SLOTS; s++) {
         group_wait(&pool, &staged[s]);
         group_wait(&pool, &written[s]);
     }
@@ -684,9 +761,15 @@ done:
     t_phase[4] = now_s();
     if (timing && rc == 0)
         fprintf(stderr, "ec504 timing: %d frames, %d threads, batch %d, %d encoder(s): first decode %.3f s, gpu encoders %.3f s, "
-                        "pinned buffers %.3f s, chunks %.3f s, last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
+                        "pinned buffers %.3f s, chunks %.3f s (the caller waited: staging %.3f, decode %.3f, .bit writers %.3f, GPU %.3f, "
+                        "video fwrite %.3f), last .bit writes %.3f s\n", frames_done, pool.n_threads + 1, batch,
                 cx.n_lanes, t_phase[1] - t_phase[0], t_created - t_phase[1], t_phase[2] - t_created, t_phase[3] - t_phase[2],
-                t_phase[4] - t_phase[3]);
+                t_wait[0], t_wait[1], t_wait[2], t_wait[3], t_wait[4], t_phase[4] - t_phase[3]);
+    if (timing && rc == 0)
+        fprintf(stderr, "ec504 tasks: decode %lld x %.2f ms, stage %lld x %.2f ms, .bit write %lld x %.2f ms, GPU chunk %lld x %.2f ms "
+                        "(mean duration of a task while the others run)\n",
+                g_task_n[0], g_task_n[0] ? g_task_us[0] / 1e3 / g_task_n[0] : 0.0, g_task_n[1], g_task_n[1] ? g_task_us[1] / 1e3 / g_task_n[1] : 0.0,
+                g_task_n[2], g_task_n[2] ? g_task_us[2] / 1e3 / g_task_n[2] : 0.0, g_task_n[3], g_task_n[3] ? g_task_us[3] / 1e3 / g_task_n[3] : 0.0);
     pool_close(&pool);
     if (cx.valid) { /* keep the device side for the next call, or give it back */
         int keep = rc == 0 && env_int("EC504_KEEP_ENCODER", 1);
@@ -710,6 +793,7 @@ done:
     free(paths);
     fclose(fp);
     return rc;
+#undef TIMED
 #undef CHUNK_FIRST
 #undef CHUNK_FILES
 }

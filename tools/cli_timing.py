@@ -23,7 +23,8 @@ try:
         Image.fromarray(img).save(f"{d}/images/f{i:04d}.jpg", quality=90)
     # (host threads, .bit files, frames per chunk, EC504_DEVICES, calls in one process)
     for threads, bit, batch, devices, repeat in ((0, 1, 16, "0", 1), (0, 1, 16, "0,0", 1), (0, 1, 16, "0,0,0", 1), (0, 0, 16, "0", 1), (0, 0, 16, "0,0", 1),
-                                                 (0, 1, 64, "0,0", 1), (0, 1, 16, "0,0", 3), (0, 0, 16, "0,0", 3), (1, 1, 16, "0", 1)):
+                                                 (16, 1, 16, "0,0", 1), (64, 1, 16, "0,0", 1), (128, 1, 16, "0,0", 1), (256, 1, 16, "0,0", 1),
+                                                 (0, 1, 64, "0,0", 1), (0, 1, 16, "0,0", 3), (0, 0, 16, "0,0", 3), (64, 1, 16, "0,0", 3), (256, 1, 16, "0,0", 3), (1, 1, 16, "0", 1)):
         shutil.rmtree(d + "/out", ignore_errors=True)
         os.makedirs(d + "/out")
         env = dict(os.environ, EC504_TIMING="1", EC504_WRITE_BIT=str(bit), EC504_BATCH=str(batch), EC504_DEVICES=devices,
