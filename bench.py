@@ -622,6 +622,7 @@ def main():
                                      "note": "input resident in HBM; frame records of batch k -> pinned host memory on a side stream while batch "
                                              "k+1 encodes (ec504_imageencoder_amd/delivery.py); one host wait per step on 16 pinned bytes"}
             assert same, "delivered bytes differ from the device-resident output"
+            hd.close()
         if world == 1 and args.host_path:
             # PCIe-inclusive rate of the host-buffer entry point (never the headline value)
             m = min(n, 64)

@@ -35,6 +35,7 @@ constexpr unsigned long long kCtrBitsMask = (1ull << 40) - 1; // strip_ctr: bits
 constexpr int kCtrCountShift = 40;
 constexpr int kAsmThreads = 256;
 constexpr int kAsmMaxGroup = 16;
+constexpr int kAsmImageBytes = 14336; // LDS image of a group's output bytes: with the placement table 18.3 KB = eight workgroups per CU
 // LDS words behind the image: [0..1] frame offset (u64), [2] bytes in front of the group, [3] bytes of the frame's strips,
 // [4] bytes of the group; from word 16: placement of <= 256 segments (16 bytes each)
 constexpr int kAsmPlace = 16, kAsmFixedWords = kAsmPlace + 4 * kAsmThreads;
@@ -157,7 +158,17 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         for (uint32_t k = tid; k < ((bytes + 15u) >> 4); k += kAsmThreads) img4[k] = make_uint4(0u, 0u, 0u, 0u);
     };
 
-    // ---- 1. prologue: one job per wave (every load unconditional: clamped index, masked afterwards) ----
+    const int lg = a.lanes_log2, L = 1 << lg, sub = tid & (L - 1), slot = tid >> lg, per_trip = kAsmThreads >> lg, w0 = 4 * sub;
+    constexpr int U = M1V_ASM_U;
+    // four source words from word x of the scratch: a scalar base + a 32-bit byte offset unless the scratch is 4 GiB or more
+    auto src_words = [&](uint32_t x) -> AsmWords4 {
+        if (WIDE) return *reinterpret_cast<const AsmWords4 *>(a.scratch + ((size_t)x << 2));
+        return *reinterpret_cast<const AsmWords4 *>(a.scratch + (x << 2));
+    };
+
+    // ---- 1. prologue: one job per wave (every load unconditional: clamped index, masked afterwards).  (Requesting the first
+    //      trip's source words here, in front of the barrier — their addresses need the segment table only, not the scan — was
+    //      tried: the workgroup's chain stays segment entry -> source word -> image -> store, 7.8 us against 7.6.) ----
     uint32_t carry = 0; // wave 2: destination bit of the next chunk's first segment
     if (wave == 0) {
         unsigned long long acc = 0; // where the frame starts: 48 bytes of headers and trailer + its strips, for every frame in front
@@ -223,13 +234,6 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
 
     const uintptr_t A0 = reinterpret_cast<uintptr_t>(a.out) + fo + 44ull + B0, a_lo = A0 & ~(uintptr_t)15;
     const uint32_t lead = (uint32_t)(A0 - a_lo), img_end = lead + group_bytes; // the group's bytes are image bytes [lead, img_end)
-    const int lg = a.lanes_log2, L = 1 << lg, sub = tid & (L - 1), slot = tid >> lg, per_trip = kAsmThreads >> lg, w0 = 4 * sub;
-    constexpr int U = M1V_ASM_U;
-    // four source words from word x of the scratch: a scalar base + a 32-bit byte offset unless the scratch is 4 GiB or more
-    auto src_words = [&](uint32_t x) -> AsmWords4 {
-        if (WIDE) return *reinterpret_cast<const AsmWords4 *>(a.scratch + ((size_t)x << 2));
-        return *reinterpret_cast<const AsmWords4 *>(a.scratch + (x << 2));
-    };
     // Destination words w .. w + 3 of a segment of `nw` source words from its words w - 1 (`p`: swapped, zero if there is none),
     // w .. w + 3: each is the funnel shift of two neighbours by the segment's phase.  Words past the segment's end count as
     // zero, so that destination word `nw` comes out as the tail the last source word leaves; the padding bits of a segment's
@@ -252,6 +256,61 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     // if that still lies inside the image
     const bool unchecked = img_end + 4u * (4u * (uint32_t)L + 4u) <= cap_bytes;
 
+    // ---- 2. four destination words of U segments per lane and trip (e0 = the trip's first segment in the chunk) ----
+    // A segment's placement, as the lane needs it: source words; phase; image word of the lane's first destination word; where
+    // its source starts.  Read from LDS in front of the loads and again behind them rather than carried in registers across them.
+    auto placement = [&](int e0, int cnt, int word0, int u, int &nw, uint32_t &sh, int &k0, uint32_t &from) {
+        const int e = e0 + u * per_trip + slot;
+        const uint4 pl = place[min(e, cnt - 1)];
+        const uint32_t d = pl.x + 8u * lead;
+        nw = e < cnt ? (int)((pl.y + 31u) >> 5) : 0;
+        sh = d & 31u;
+        k0 = (int)(d >> 5) - word0 + w0;
+        from = pl.z;
+    };
+    auto load_trip = [&](AsmWords4 (&cur)[U], int e0, int cnt, int word0) { // all loads of the trip, nothing waited for
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int nw, k0;
+            uint32_t sh, from;
+            placement(e0, cnt, word0, u, nw, sh, k0, from);
+            // lanes behind the segment's end read its first words (an empty segment's: the first words of the scratch)
+            cur[u] = src_words(from + (w0 < nw ? (uint32_t)w0 : 0u));
+        }
+    };
+    auto place_trip = [&](const AsmWords4 (&cur)[U], int e0, int cnt, int word0, int capw) {
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int nw, k0;
+            uint32_t sh, from;
+            placement(e0, cnt, word0, u, nw, sh, k0, from);
+            more |= nw >= 4 * L;
+            // the word in front of the lane's four: the neighbouring lane's last, swapped and masked there (row_shr:1)
+            const uint32_t last = w0 + 3 < nw ? __builtin_bswap32(cur[u].w[3]) : 0u;
+            const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x111, 0xf, 0xf, true);
+            if (unchecked)
+                scatter4(std::false_type(), cur[u], sub ? p : 0u, nw, w0, sh, k0, capw);
+            else
+                scatter4(std::true_type(), cur[u], sub ? p : 0u, nw, w0, sh, k0, capw);
+        }
+        // segments of more than 4 * L - 1 words (rare at the quality the host sized L for): the rest of their words
+        if (__builtin_amdgcn_ballot_w64(more)) {
+#pragma unroll 1
+            for (int u = 0; u < U; u++) {
+                int nw, k0;
+                uint32_t sh, from;
+                placement(e0, cnt, word0, u, nw, sh, k0, from);
+                for (int w = w0 + 4 * L; w <= nw; w += 4 * L) {
+                    const AsmWords4 c = src_words(from + (uint32_t)(w < nw ? w : 0));
+                    const uint32_t p = __builtin_bswap32(src_words(from + (uint32_t)(w - 1)).w[0]);
+                    scatter4(std::true_type(), c, p, nw, w, sh, k0 - w0 + w, capw);
+                }
+            }
+        }
+    };
+
+    ASTAMP(2);
     for (uint32_t pass0 = 0; pass0 < img_end; pass0 += cap_bytes) { // image bytes [pass0, pass0 + cap_bytes) of this pass
         const uint32_t pass_bytes = min(cap_bytes, img_end - pass0);
         const int word0 = (int)(pass0 >> 2), capw = (int)((pass_bytes + 3u) >> 2); // the pass's words of the image
@@ -265,59 +324,10 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
                 __syncthreads();
             }
             const int cnt = min(kAsmThreads, nseg - c0);
-            ASTAMP(2);
-
-            // ---- 2. four destination words of U segments per lane and trip: all loads first ----
             for (int e0 = 0; e0 < cnt; e0 += per_trip * U) {
                 AsmWords4 cur[U];
-                uint32_t sh[U];
-                int nw[U], k0[U]; // source words of the segment; image word of the lane's first destination word
-                bool more = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int e = e0 + u * per_trip + slot;
-                    const uint4 pl = place[min(e, cnt - 1)];
-                    const uint32_t d = pl.x + 8u * lead;
-                    nw[u] = e < cnt ? (int)((pl.y + 31u) >> 5) : 0;
-                    sh[u] = d & 31u;
-                    k0[u] = (int)(d >> 5) - word0 + w0;
-                    more |= nw[u] >= 4 * L;
-                    // lanes behind the segment's end read its first words (an empty segment's: the first words of the scratch)
-                    cur[u] = src_words(pl.z + (w0 < nw[u] ? (uint32_t)w0 : 0u));
-                }
-#ifdef M1V_ASM_SB
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (unchecked) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        // the word in front of the lane's four: the neighbouring lane's last, swapped and masked there (row_shr:1)
-                        const uint32_t last = w0 + 3 < nw[u] ? __builtin_bswap32(cur[u].w[3]) : 0u;
-                        const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x111, 0xf, 0xf, true);
-                        scatter4(std::false_type(), cur[u], sub ? p : 0u, nw[u], w0, sh[u], k0[u], capw);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t last = w0 + 3 < nw[u] ? __builtin_bswap32(cur[u].w[3]) : 0u;
-                        const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x111, 0xf, 0xf, true);
-                        scatter4(std::true_type(), cur[u], sub ? p : 0u, nw[u], w0, sh[u], k0[u], capw);
-                    }
-                }
-                // segments of more than 4 * L - 1 words (rare at the quality the host sized L for): the rest of their words
-                if (__builtin_amdgcn_ballot_w64(more)) {
-#pragma unroll 1
-                    for (int u = 0; u < U; u++) {
-                        const int e = e0 + u * per_trip + slot;
-                        if (nw[u] < 4 * L) continue;
-                        const uint32_t from = place[e].z;
-                        for (int w = w0 + 4 * L; w <= nw[u]; w += 4 * L) {
-                            const AsmWords4 c = src_words(from + (uint32_t)(w < nw[u] ? w : 0));
-                            const uint32_t p = __builtin_bswap32(src_words(from + (uint32_t)(w - 1)).w[0]);
-                            scatter4(std::true_type(), c, p, nw[u], w, sh[u], k0[u] - w0 + w, capw);
-                        }
-                    }
-                }
+                load_trip(cur, e0, cnt, word0);
+                place_trip(cur, e0, cnt, word0, capw);
             }
             ASTAMP(3);
             __syncthreads(); // the chunk's placement has been used; behind the last chunk: the image is complete

@@ -1685,7 +1685,7 @@ static int configure_path(m1v_encoder *e) {
         if ((need >> 2) >= (1ull << 32)) return fail(M1V_E_ARG, "scratch beyond 16 GiB: lower max_frames%s");
         segs = 1; // a strip is one piece
     }
-    // k_assemble (m1v_assemble.h): strips per workgroup so that a group's bytes fit its 16-KiB LDS image in one pass on noise at
+    // k_assemble (m1v_assemble.h): strips per workgroup so that a group's bytes fit its 14-KiB LDS image (eight workgroups per CU) in one pass on noise at
     // this quality (19 bits per block at quality 12; anything larger takes more passes), a power of two (the eight
     // strips of a tile column share their scratch lines); lanes per segment (four words each) ~ the words a segment holds.
     int asm_group, asm_lanes_log2;
@@ -1694,7 +1694,7 @@ static int configure_path(m1v_encoder *e) {
         const size_t bpb = 22u * (size_t)qscale;
         const size_t strip_est = (38 + (size_t)g.n_mbrows * (2 + 6 * bpb)) / 8 + 1;
         asm_group = 1;
-        while (asm_group < kAsmMaxGroup && (size_t)(2 * asm_group) * strip_est * 5 / 4 <= 16384 && 2 * asm_group <= g.n_strips) asm_group *= 2;
+        while (asm_group < kAsmMaxGroup && (size_t)(2 * asm_group) * strip_est * 5 / 4 <= kAsmImageBytes && 2 * asm_group <= g.n_strips) asm_group *= 2;
         const size_t seg_blocks = plan.tiles ? (size_t)kTileSegBlocks : (e->dense ? (size_t)plan.dense_T : (size_t)bps);
         const size_t seg_words = seg_blocks * bpb / 32;
         asm_lanes_log2 = 1; // four words per lane: enough lanes for 1.6 x the expected words, at most one DPP row
@@ -1802,7 +1802,7 @@ static int configure_path(m1v_encoder *e) {
     e->segs = segs;
     e->asm_group = asm_group;
     e->asm_lanes_log2 = asm_lanes_log2;
-    e->asm_img_words = 4096;
+    e->asm_img_words = kAsmImageBytes / 4;
     return M1V_OK;
 }
 
@@ -2342,6 +2342,7 @@ int m1v_encode_device(m1v_encoder *e, const uint8_t *d_rgb, int n_frames, int fi
 // ---- overlapped delivery to the host (include/mpeg1_hip.h) ----------------------------------------------------------
 struct m1v_delivery {
     m1v_encoder *e;
+    int device; // (the encoder may be destroyed before the delivery object is)
     size_t cap;
     int max_frames;
     uint8_t *d_out[2], *h_out[2];
@@ -2396,6 +2397,7 @@ int m1v_delivery_create(m1v_encoder *e, size_t out_cap, m1v_delivery **out) {
     m1v_delivery *d = new m1v_delivery();
     memset(d, 0, sizeof *d);
     d->e = e;
+    d->device = e->device;
     d->max_frames = e->max_frames;
     d->cap = out_cap ? out_cap : (size_t)e->max_frames * m1v_frame_bound(e);
     d->pending = -1;
@@ -2423,7 +2425,7 @@ int m1v_delivery_create(m1v_encoder *e, size_t out_cap, m1v_delivery **out) {
 
 void m1v_delivery_destroy(m1v_delivery *d) {
     if (!d) return;
-    (void)hipSetDevice(d->e->device);
+    (void)hipSetDevice(d->device);
     if (d->side) (void)hipStreamSynchronize(d->side);
     for (int b = 0; b < 2; b++) {
         (void)hipFree(d->d_out[b]);
@@ -2476,7 +2478,7 @@ uint64_t m1v_delivery_bytes(const m1v_delivery *d, int slot) { return d && slot 
 
 int m1v_delivery_wait(m1v_delivery *d, int slot, const uint8_t **host, uint64_t *bytes, const uint64_t **frame_sizes) {
     if (!d || slot < 0 || slot > 1) return fail(M1V_E_ARG, "bad slot%s");
-    HIP_TRY(hipSetDevice(d->e->device));
+    HIP_TRY(hipSetDevice(d->device));
     HIP_TRY(hipEventSynchronize(d->delivered[slot]));
     if (host) *host = d->h_out[slot];
     if (bytes) *bytes = d->h_meta[slot][0];

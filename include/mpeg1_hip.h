@@ -135,7 +135,8 @@ int m1v_flush(m1v_encoder *enc, void *stream);
  *   slot = m1v_delivery_flush(d)               starts the copy of the last batch (M1V_DELIVERY_NONE if none is pending)
  *   m1v_delivery_wait(d, slot, &host, &bytes, &frame_sizes)
  *                                              blocks until that slot's copy has arrived; host / frame_sizes point into the
- *                                              slot's pinned buffers, valid until the second step after the one that returned it */
+ *                                              slot's pinned buffers, valid until the second step after the one that returned it
+ * The delivery object must not be stepped or flushed after its encoder has been destroyed (wait and destroy are fine). */
 typedef struct m1v_delivery m1v_delivery;
 enum { M1V_DELIVERY_NONE = 2 };
 int m1v_delivery_create(m1v_encoder *enc, size_t out_cap, m1v_delivery **out);

@@ -213,6 +213,7 @@ def test_host_delivery_retries_a_batch_that_ran_out_of_scratch(torch_cuda, orc):
     hd.fence()
     got.append(bytes(hd.result().numpy()))
     assert got == wants
+    hd.close()
     enc.close()
 
 
@@ -253,6 +254,7 @@ def test_host_delivery_overlapped_with_the_next_encode(torch_cuda, orc):
     hd.fence()
     got.append(bytes(hd.result().numpy()))
     assert got == wants
+    hd.close()
     enc.close()
 
 
