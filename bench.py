@@ -189,11 +189,11 @@ def _pmc_sources_sha256(sources):
 
 
 def _committed_pmc(W, H, n, kernel="k_encode_dense"):
-    """The committed rocprofv3 PMC record of this workload and kernel (profiles/r03_pmc.json, written by
-    tools/pmc_record_r03.py from the summaries of tools/pmc_r03.sh), or None.  PMC cannot be collected from inside this
+    """The committed rocprofv3 PMC record of this workload and kernel (profiles/r04_pmc.json, written by
+    tools/pmc_record_r04.py from the summaries of tools/pmc_r04.sh), or None.  PMC cannot be collected from inside this
     process; the record names the kernel sources it was measured on, and `fresh` says whether they are still the tree's."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
             doc = json.load(f)
         fresh = _pmc_sources_sha256(doc["sources"]) == doc["source_sha256"]
         for rec in doc["workloads"]:

@@ -1591,23 +1591,39 @@ size_t m1v_file_prolog(uint8_t out[27]) {
 #define M1V_TILE_RING 2
 #endif
 // The order in which a frame's tile rows are processed.  Tile row R (macroblock rows 4R..4R+3) reads its luma from picture
-// rows [64R, 64R+64) and — the chroma quirk, encoder.h:347-348 — its chroma from rows [16R, 16R+16), i.e. from the luma
-// region of tile row R/4.  Top to bottom the second read comes 0.75 R tile rows after the first: at 3840x2160 (737 KB per
-// tile row, 4 MB of L2 per XCD) four chroma reads in five miss L2 and the kernel moves 1.22x its algorithmic bytes.  A
-// depth-first walk of the tree "R is the parent of 4R .. 4R+3" puts every tile row right behind the region its chroma comes
-// from (first children) or a few rows later (later children of a leaf parent): the misses fall to the later children of the
-// few inner nodes.
+// rows [64R, 64R+64) and — the chroma quirk, encoder.h:347-348 — its chroma from rows [16R, 16R+16), i.e. from one quarter of
+// the luma region of tile row R/4.  Every byte of the top quarter of the picture is therefore read twice, once as luma and once
+// as some other tile row's chroma, and the second read is an L2 hit only if few tile rows pass between the two (an XCD's L2 holds
+// 5.7 tile rows of a 3840x2160 frame, 11 of a 1920x1080 one).  Which read comes first does not matter.  So this is the layout of
+// the tree "R is the parent of 4R .. 4R+3" on a line that keeps parents and children close: every node sits in the MIDDLE of
+// its children, the two smallest subtrees directly beside it, the larger ones outside.  Top to bottom (round 2) four chroma
+// reads in five miss at 4K (HBM traffic 1.22x the algorithmic bytes); a depth-first walk (round 3) still loses the later
+// children of every inner node (1.07x); this order loses three edges of 33 (1.02x in an LRU model of the L2, tools/l2_order_sim.py).
 static void tile_row_order_for(int tile_rows, std::vector<uint32_t> &order) {
-    order.clear();
-    std::vector<int> stack;
-    stack.push_back(0);
-    while (!stack.empty()) {
-        const int r = stack.back();
-        stack.pop_back();
-        order.push_back((uint32_t)r);
-        for (int c = 4 * r + 3; c >= 4 * r; c--) // children pushed in reverse: taken in ascending order
-            if (c > 0 && c < tile_rows) stack.push_back(c);
-    }
+    std::vector<int> size((size_t)tile_rows, 1);
+    for (int r = tile_rows - 1; r >= 1; r--) size[(size_t)(r / 4)] += size[(size_t)r]; // children have larger indices than parents
+    struct Arrange {
+        int tile_rows;
+        const std::vector<int> &size;
+        std::vector<uint32_t> run(int r) const {
+            std::vector<int> ch;
+            for (int c = 4 * r; c < 4 * r + 4; c++)
+                if (c > 0 && c < tile_rows) ch.push_back(c);
+            std::stable_sort(ch.begin(), ch.end(), [&](int x, int y) { return size[(size_t)x] < size[(size_t)y]; });
+            std::vector<uint32_t> left, right;
+            for (size_t i = 0; i < ch.size(); i++) {
+                const std::vector<uint32_t> a = run(ch[i]);
+                if (i == 0) left.insert(left.end(), a.begin(), a.end());          // smallest: directly in front of r
+                else if (i == 1) right.insert(right.begin(), a.begin(), a.end()); // next: directly behind r
+                else if (i == 2) left.insert(left.begin(), a.begin(), a.end());   // the larger ones outside
+                else right.insert(right.end(), a.begin(), a.end());
+            }
+            left.push_back((uint32_t)r);
+            left.insert(left.end(), right.begin(), right.end());
+            return left;
+        }
+    };
+    order = Arrange{tile_rows, size}.run(0);
 }
 
 static int g_fail_alloc_in = 0; // test hook (m1v_debug_fail_alloc): the n-th allocation of configure_path from now fails

@@ -180,31 +180,44 @@ __device__ __forceinline__ void tile_pixel_rows(const Geometry &g, const uint8_t
     uint32_t pitch;          // bytes from row i to row i + 1 of a block
     uint32_t voff_a, voff_b; // this lane's 16 bytes of row 0 (first / second instruction): byte offset from the frame base
     uint32_t lane_row;       // LDS address of the lane's 24 bytes inside slot 0
+    // The four row offsets a wave's lanes choose from are products of UNIFORM values (scalar multiplies); a lane picks its own by
+    // compare and select: per-lane 32-bit multiplies and the division of the lane index by 24 are quarter-rate instructions.
+    const uint32_t third = (uint32_t)(lane >= 24) + (uint32_t)(lane >= 48); // lane / 24
+    auto uniform = [](uint32_t v) { // an opaque scalar (the compiler removes a readfirstlane of a value it knows to be uniform)
+        asm volatile("" : "+s"(v));
+        return v;
+    };
     if (!chroma) {
         pitch = (uint32_t)g.W * 3u;
         const uint32_t vw = (uint32_t)strips_here * 48u;
-        auto off = [&](uint32_t L) { // L-th 16-byte unit of the 1536-byte row-step: piece = picture row, `within` inside its 384 bytes
-            const uint32_t piece = L / 24u, within = min((L - piece * 24u) * 16u, vw - 16u);
+        // 16-byte unit L of the 1536-byte row-step: piece = L / 24 = picture row of the step, `within` inside its 384 bytes
+        auto row_off = [&](uint32_t piece) { // uniform
             const uint32_t mb = (uint32_t)min(m0 + 2 * wave + (int)(piece >> 1), g.n_mbrows - 1);
-            return ((mb * 16u + (piece & 1u) * 8u) * (uint32_t)g.W + (uint32_t)s0 * 16u) * 3u + within;
+            return ((mb * 16u + (piece & 1u) * 8u) * (uint32_t)g.W + (uint32_t)s0 * 16u) * 3u;
         };
-        voff_a = off((uint32_t)lane);
-        voff_b = off(64u + (uint32_t)(lane & 31));
-        lane_row = ring + (uint32_t)lane * 24u;
+        // (opaque: left visible, the compiler folds the selects back into per-lane multiplies)
+        const uint32_t r0 = uniform(row_off(0)), r1 = uniform(row_off(1)), r2 = uniform(row_off(2)), r3 = uniform(row_off(3));
+        // first instruction: units 0..63 -> pieces 0, 1, 2
+        voff_a = (third == 0 ? r0 : (third == 1 ? r1 : r2)) + min(((uint32_t)lane - (third << 4) - (third << 3)) * 16u, vw - 16u);
+        // second instruction: units 64 + (lane & 31) = 64..95 -> piece 2 (units 64..71) or 3
+        const uint32_t l5 = (uint32_t)lane & 31u;
+        voff_b = l5 < 8u ? r2 + min((16u + l5) * 16u, vw - 16u) : r3 + min((l5 - 8u) * 16u, vw - 16u);
+        lane_row = ring + ((uint32_t)lane << 4) + ((uint32_t)lane << 3);
     } else {
         pitch = (uint32_t)g.half_w * 3u;
         const uint32_t vw = (uint32_t)strips_here * 24u;
         // (an odd number of strips ends in the middle of a 16-byte unit: that unit is still fetched whole — up to 8 bytes
         //  past the tile's last strip, still inside the first quarter of the frame, where all chroma sources lie)
-        const uint32_t L = (uint32_t)lane % 24u, piece = L / 12u, within = min((L - piece * 12u) * 16u, ((vw + 15u) & ~15u) - 16u);
-        auto off = [&](uint32_t mbrow) {
+        const uint32_t L = (uint32_t)lane - (third << 4) - (third << 3), piece = (uint32_t)(L >= 12u), within = min((L - (piece << 3) - (piece << 2)) * 16u, ((vw + 15u) & ~15u) - 16u);
+        auto row_off = [&](uint32_t mbrow) { // uniform
             const uint32_t mb = (uint32_t)min(m0 + (int)mbrow, g.n_mbrows - 1);
-            return ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u + within;
+            return ((mb * 8u) * (uint32_t)g.half_w + (uint32_t)s0 * 8u) * 3u;
         };
-        voff_a = off(piece);
-        voff_b = off(2u + piece);
-        const uint32_t mrow = ((uint32_t)lane >> 3) & 3u;
-        lane_row = ring + (mrow >> 1) * 1024u + (mrow & 1u) * 192u + ((uint32_t)lane & 7u) * 24u;
+        const uint32_t r0 = uniform(row_off(0)), r1 = uniform(row_off(1)), r2 = uniform(row_off(2)), r3 = uniform(row_off(3));
+        voff_a = (piece ? r1 : r0) + within;
+        voff_b = (piece ? r3 : r2) + within;
+        const uint32_t mrow = ((uint32_t)lane >> 3) & 3u, l3 = (uint32_t)lane & 7u;
+        lane_row = ring + (mrow >> 1) * 1024u + (mrow & 1u) * 192u + (l3 << 4) + (l3 << 3);
     }
     constexpr uint32_t kSlot = 2048;
     auto issue_row = [&](int r) { // row-step r -> slot r % R.  M0 (the LDS destination) is set once: the second instruction's
@@ -379,19 +392,22 @@ void k_encode_tiles(TileArgs a) {
     // The strip's bit total (wave 0, lanes < strips_here): one returning atomic per segment; the tile whose add finds every other
     // tile row of the strip already counted knows the strip's bits and adds its bytes (zero bits pad a strip to a byte,
     // encoder.h:442-443) to the frame's total.  Only the values the atomics return travel between tiles: no fence.
+    // (uniform 64-bit bases + 32-bit lane offsets: per-lane 64-bit index products are quarter-rate multiplies)
+    unsigned long long *const strip_ctr_s0 = a.strip_ctr + ((unsigned long long)frame * (unsigned)g.n_strips + (unsigned)s0);
     auto strip_arrives = [&](uint32_t bits) -> unsigned long long {
 #ifdef M1V_TILE_NOCOMPLETE // timing build (wrong sizes): what the returning atomic and the completion cost
-        __hip_atomic_fetch_add(&a.strip_ctr[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], (1ull << kCtrCountShift) | (unsigned long long)bits,
+        __hip_atomic_fetch_add(strip_ctr_s0 + lane, (1ull << kCtrCountShift) | (unsigned long long)bits,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return 0ull;
 #endif
-        return atomicAdd(&a.strip_ctr[(size_t)frame * g.n_strips + (size_t)(s0 + lane)], (1ull << kCtrCountShift) | (unsigned long long)bits);
+        return atomicAdd(strip_ctr_s0 + lane, (1ull << kCtrCountShift) | (unsigned long long)bits);
     };
     auto strip_completes = [&](unsigned long long before, uint32_t bits) {
         if ((uint32_t)(before >> kCtrCountShift) == (uint32_t)a.tile_rows - 1u)
             atomicAdd(&a.frame_bytes[frame], ((before & kCtrBitsMask) + bits + 7ull) >> 3);
     };
-    uint2 *seg_out = a.seg + ((unsigned long long)frame * g.n_strips + (unsigned)(s0 + lane)) * a.tile_rows + tr; // lanes < strips_here
+    uint2 *seg_out = a.seg + (((unsigned long long)frame * (unsigned)g.n_strips + (unsigned)s0) * (unsigned)a.tile_rows + (unsigned)tr) +
+                     (uint32_t)lane * (uint32_t)a.tile_rows; // lanes < strips_here
     auto slice_headers = [&](uint32_t *img, bool swapped) { // wave 0, lanes < strips_here
         if (tr == 0) {
             const uint32_t h0 = slice_word0(s0 + lane), h1 = kSliceWord1, w = seg_incl - seg_words;
