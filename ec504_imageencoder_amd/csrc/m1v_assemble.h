@@ -7,7 +7,8 @@
 // launches (strip layout, frame offsets, a gather of one wave per strip at 0.195 of the HBM rate).
 //
 // Input, all produced by the encode kernel of the same batch (any of the three):
-//   seg[frame][strip][q] = (bits, where)   what a strip is concatenated from: `bits` bits that start at word `where` of scratch
+//   seg[frame][q][strip] = (bits, where)   what a strip is concatenated from: `bits` bits that start at word `where` of scratch
+//                                          (segment-major: the eight entries a tile writes are 64 contiguous bytes)
 //   strip_ctr[frame][strip]                low 40 bits: bits of the strip (the tile kernel adds them up with one returning atomic
 //                                          per segment; its upper bits count the arrivals)
 //   frame_bytes[frame]                     sum over the frame's strips of ceil(bits / 8): added by whoever completed a strip
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     uint4 *place = reinterpret_cast<uint4 *>(fixed + kAsmPlace); // per segment: destination bit (from the group's first byte), bits, source word, -
     const unsigned long long *ctr_f = a.strip_ctr + (size_t)f * a.n_strips;
     const int nseg = ns * T;
-    const uint2 *seg_g = a.seg + ((size_t)f * a.n_strips + s0) * T;
+    const uint2 *seg_f = a.seg + (size_t)f * T * a.n_strips + s0; // segment q = j * T + t of the group: seg_f[t * n_strips + j]
     const uint32_t cap_bytes = (uint32_t)a.img_words * 4u;
 
     // Destination bits of segments [c0, c0 + 256) -> place[]: one wave, four blocks of 64, loads first.  A strip's padding (zero
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (k >= blocks) break;
-            const int q = c0 + 64 * k + lane, j = (int)udiv((uint32_t)min(q, nseg - 1), a.div_segs);
-            last[k] = q - j * T == T - 1;
-            sg[k] = seg_g[min(q, nseg - 1)];
+            const int q = min(c0 + 64 * k + lane, nseg - 1), j = (int)udiv((uint32_t)q, a.div_segs), t = q - j * T;
+            last[k] = t == T - 1;
+            sg[k] = seg_f[(size_t)t * a.n_strips + j];
             ctr[k] = ctr_f[s0 + j];
         }
 #pragma unroll

@@ -1195,7 +1195,7 @@ __device__ __forceinline__ uint32_t dense_segment(const DenseGeom &d, const uint
     return m[1];
 }
 
-// One workgroup per frame: the run segments of every strip, in the form k_assemble takes them: seg[frame][strip][q] =
+// One workgroup per frame: the run segments of every strip, in the form k_assemble takes them: seg[frame][q][strip] =
 // (bits, where), padded with empty segments up to `segs` per strip; the strips' bit totals; the frame's bytes.
 __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int segs, const uint32_t *run_meta, uint2 *seg,
                                                             unsigned long long *strip_ctr, unsigned long long *frame_bytes) {
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_dense_frame_layout(DenseGeom d, int seg
         for (int q = 0; q < segs; q++) {
             uint32_t boff = 0, L = 0;
             if (w_lo + q <= w_hi) L = dense_segment(d, mf, w_lo + q, s, boff);
-            seg[i * segs + q] = make_uint2(L, boff);
+            seg[((size_t)f * segs + q) * d.n_strips + s] = make_uint2(L, boff);
             bits += L;
         }
         strip_ctr[i] = bits;
@@ -1519,7 +1519,7 @@ struct m1v_encoder {
     struct Batch {
         uint8_t *scratch;
         uint32_t *run_meta;     // run kernels: [frame][run][4]
-        uint2 *seg;             // [frame][strip][segment] (bits, where): what a strip is concatenated from
+        uint2 *seg;             // [frame][segment][strip] (bits, where): what a strip is concatenated from
         Counters ctr[2];
         unsigned turn;
         hipEvent_t enc_done, gather_done;

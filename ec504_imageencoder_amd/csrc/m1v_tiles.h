@@ -39,7 +39,7 @@ struct TileArgs {
     const uint8_t *rgb;
     const Tables *tab;
     uint8_t *scratch;       // [frame][tile][slot_bytes] compact slots, then the overflow arena (as the run kernels)
-    uint2 *seg;             // [frame][strip][tile row]: bits of the segment, where it starts (4-byte words from `scratch`)
+    uint2 *seg;             // [frame][tile row][strip]: bits of the segment, where it starts (4-byte words from `scratch`)
     unsigned long long *strip_ctr;   // [frame][strip]: every tile adds (1 << 40 | its segment's bits) with ONE returning atomic: the tile
                                      // that sees tile_rows - 1 arrivals in front of it completes the strip and knows its bits
     unsigned long long *frame_bytes; // [frame]: that tile adds the strip's bytes (both zero before the batch: k_assemble of the batch
@@ -406,8 +406,9 @@ void k_encode_tiles(TileArgs a) {
         if ((uint32_t)(before >> kCtrCountShift) == (uint32_t)a.tile_rows - 1u)
             atomicAdd(&a.frame_bytes[frame], ((before & kCtrBitsMask) + bits + 7ull) >> 3);
     };
-    uint2 *seg_out = a.seg + (((unsigned long long)frame * (unsigned)g.n_strips + (unsigned)s0) * (unsigned)a.tile_rows + (unsigned)tr) +
-                     (uint32_t)lane * (uint32_t)a.tile_rows; // lanes < strips_here
+    // seg[frame][tile row][strip]: the tile's eight entries are 64 contiguous bytes (strip-major they were eight 32-byte
+    // sectors 8 * tile_rows bytes apart: 256 bytes of write traffic for 64)
+    uint2 *seg_out = a.seg + (((unsigned long long)frame * (unsigned)a.tile_rows + (unsigned)tr) * (unsigned)g.n_strips + (unsigned)s0) + lane; // lanes < strips_here
     auto slice_headers = [&](uint32_t *img, bool swapped) { // wave 0, lanes < strips_here
         if (tr == 0) {
             const uint32_t h0 = slice_word0(s0 + lane), h1 = kSliceWord1, w = seg_incl - seg_words;

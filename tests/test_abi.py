@@ -271,3 +271,39 @@ def test_rounding_mode_of_the_pixel_stage(built):
         assert not late, (name, late)
     assert sorted(n[n.index("k_"):][:18] for n in switching) == ["k_coefficient_tile", "k_encode_tilesILb0", "k_encode_tilesILb1"], switching
 
+
+
+def test_assemble_kernel_shape_of_round_4(built):
+    """Round-4 properties of k_assemble (csrc/m1v_assemble.h), read off the code object.  It replaced round 3's gather, whose
+    lanes exchanged a table through wave-private LDS ordered by a release fence only (advisor, round 3): here every LDS value
+    that one lane writes and another reads crosses a workgroup barrier.
+    * the old kernels are gone from the library (k_gather_segments, k_tile_layout, k_frame_offsets, k_gather, k_frame_layout);
+    * between the LDS writes of the placement table (ds_write_b128) and the first source load there is an s_barrier; the
+      kernel has at least three (placement, image complete, per further chunk / pass);
+    * placement is ds_or_b32 only (no returning LDS atomic, no LDS compare-and-swap), and no wave-scope fence is relied on;
+    * 64 VGPRs or fewer (8 waves per SIMD) and no scratch; both instantiations (32-bit and 64-bit scratch offsets) exist."""
+    asm, notes = _gfx950_disassembly()
+    names = re.findall(r"<(_ZN\S*)>:", asm)
+    for gone in ("k_gather_segments", "k_tile_layout", "k_frame_offsets", "k_frame_layout", "8k_gatherE"):
+        assert not any(gone in n for n in names), gone
+    for variant in ("k_assembleILb0", "k_assembleILb1"):
+        m = re.search(r"<_ZN\S*%s\S*>:\n(.*?)\n\n" % variant, asm, re.S)
+        assert m, variant
+        lines = [l.split("//")[0].strip() for l in m.group(1).splitlines() if l.strip() and not l.strip().startswith(("/", ";"))]
+        ops = [l.split()[0] for l in lines]
+        table_writes = [i for i, o in enumerate(ops) if o == "ds_write_b128"]
+        barriers = [i for i, o in enumerate(ops) if o == "s_barrier"]
+        ors = [i for i, o in enumerate(ops) if o == "ds_or_b32"]
+        source_loads = [i for i, o in enumerate(ops) if o == "global_load_dwordx4"]
+        assert table_writes and barriers and ors and source_loads, variant
+        # (in the code's order the scan of a LATER chunk follows the scatter: look at the first occurrence of each)
+        first_src = min(i for i in source_loads if i > table_writes[0])
+        assert any(table_writes[0] < b < first_src for b in barriers), variant
+        # (the compiler lays the blocks of the pass / chunk loops out of source order, so only counts are checked for the second
+        #  barrier: scatter -> barrier -> store loop is one of at least three barriers of the kernel; the GPU suite checks bytes)
+        assert len(barriers) >= 3, variant
+        assert not any(o.startswith(("ds_or_rtn", "ds_cmpst", "ds_cmpswap")) for o in ops), variant
+    recs = re.findall(r"\.name:\s*(\S*k_assemble\S*).*?\.private_segment_fixed_size:\s*(\d+).*?\.vgpr_count:\s*(\d+)", notes, re.S)
+    assert len(recs) == 2, recs
+    for nm, scratch, vgprs in recs:
+        assert int(scratch) == 0 and int(vgprs) <= 64, (nm, scratch, vgprs)

@@ -141,6 +141,34 @@ def test_colour_inside_the_encode_kernels_exhaustive_2_24(torch_cuda, orc, path)
     _check_colours_through(torch_cuda, orc, colours, lambda e: e.debug_set_path(path))
 
 
+@pytest.mark.parametrize("W,H,channels,mode,qf,n,path", [
+    (1920, 1080, 3, "full", 100, 2, "tiles"),    # a strip of ~20 KB: one strip per workgroup, several PASSES over the 14-KiB image
+    (1920, 1080, 3, "full", 90, 2, "runs"),      # the same through the run kernel's long segments (64 words and more per lane group)
+    (128, 4368, 3, "full", 12, 3, "tiles"),      # 69 tile rows x 8 strips = 552 segments in one group: three CHUNKS of the placement table
+    (128, 4368, 3, "full", 75, 2, "tiles"),      # ... and several passes on top
+    (640, 480, 4, "strict", 50, 5, "auto"),      # 4 channels, 54 blocks per strip: the strip-per-workgroup kernel, one segment per strip
+    (4112, 160, 3, "full", 30, 2, "tiles"),      # 257 strips: 33 groups, the last of one strip; start codes wrap at 256
+    (16, 16, 3, "full", 12, 7, "tiles"),         # one macroblock per frame
+])
+def test_assemble_kernel_passes_chunks_and_long_segments(torch_cuda, orc, W, H, channels, mode, qf, n, path):
+    """k_assemble (csrc/m1v_assemble.h) outside the shape the host sizes it for: groups whose bytes outgrow the LDS image
+    (passes), groups of more than 256 segments (chunks), segments longer than their lanes' first trip, the three producers of
+    segment tables (tiles, runs, strips), every frame's size and the total against the oracle, and a second batch on the same
+    encoder (the counters the first batch's assembly cleared)."""
+    torch = torch_cuda
+    enc = _enc(W, H, qf, mode, channels=channels, max_frames=n)
+    if path != "auto":
+        enc.debug_set_path(path)
+    rng = np.random.default_rng(W * 31 + H + qf)
+    for first in (0, 250):
+        rgb = rng.integers(0, 256, (n, H, W, channels), dtype=np.uint8)
+        want, wsizes = orc.encode_frames(rgb, n, W, H, first, qf, _omode(orc, mode), channels=channels)
+        got, sizes = enc.encode_to_bytes(torch.from_numpy(rgb).cuda(), first)
+        assert sizes == [int(x) for x in wsizes], (first, sizes[:3], list(wsizes[:3]))
+        assert got == want, first
+    enc.close()
+
+
 @pytest.mark.parametrize("path", ["tiles", "runs"])
 def test_failed_reconfiguration_leaves_the_encoder_usable(torch_cuda, orc, path):
     """m1v_reserve_scratch allocates the worst-case arena, m1v_set_pipelined a second set of buffers; when one of those

@@ -1,3 +1,5 @@
+"""What the caller of the chunk loop waits for and how long each kind of host task takes while the others run (EC504_TIMING=1),
+for a few thread counts / device lists / slot counts: python tools/cli_waits.py (GPU box; profiles/r04_cli_phase_times.txt)."""
 import os, shutil, subprocess, sys, tempfile, time
 import numpy as np
 from PIL import Image
