@@ -21,7 +21,7 @@ MPEG1_HIP_SYMBOLS = [
     "m1v_device_count", "m1v_warm_up", "m1v_last_error", "m1v_create", "m1v_destroy", "m1v_strips", "m1v_mb_rows",
     "m1v_frame_bound", "m1v_frame_bound_for", "m1v_frame_bytes_in", "m1v_file_prolog", "m1v_encode_device", "m1v_encode_host",
     "m1v_encode_planes_host",
-    "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host",
+    "m1v_set_pipelined", "m1v_flush", "m1v_alloc_host", "m1v_free_host", "m1v_alloc_device", "m1v_free_device",
     "m1v_coefficients_device", "m1v_convert_device", "m1v_convert_host", "m1v_subsample_device", "m1v_synth_device",
     "m1v_profile_enable", "m1v_profile_read", "m1v_profile_read_times", "m1v_debug_set_lds_words", "m1v_debug_set_dense_threads",
     "m1v_debug_set_input_mode", "m1v_reserve_scratch", "m1v_scratch_bytes", "m1v_debug_set_path", "m1v_path_in_use", "m1v_debug_fail_alloc",

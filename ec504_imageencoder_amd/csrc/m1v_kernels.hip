@@ -2509,6 +2509,15 @@ void *m1v_alloc_host(size_t bytes) {
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
+void *m1v_alloc_device(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void m1v_free_device(void *p) { (void)hipFree(p); }
 void m1v_free_host(void *p) {
     if (p) (void)hipHostFree(p);
 }

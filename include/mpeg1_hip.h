@@ -146,6 +146,11 @@ int m1v_delivery_flush(m1v_delivery *d);
 int m1v_delivery_wait(m1v_delivery *d, int slot, const uint8_t **host, uint64_t *bytes, const uint64_t **frame_sizes);
 uint64_t m1v_delivery_bytes(const m1v_delivery *d, int slot); /* bytes of the batch in `slot`: known once its copy has been started */
 
+/* Device memory for callers that do not link the HIP runtime themselves (a plain-C caller of m1v_encode_device /
+ * m1v_delivery_step, tests/delivery_main.c): hipMalloc / hipFree on the current device.  NULL on failure. */
+void *m1v_alloc_device(size_t bytes);
+void m1v_free_device(void *p);
+
 /* Starts the GPU runtime for `device` (context, code objects) so that a later m1v_create() does not pay for it.
  * Optional; meant to be called from another thread while the caller is still busy with host work. */
 int m1v_warm_up(int device);

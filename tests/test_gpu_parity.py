@@ -264,6 +264,25 @@ def test_bench_starts_its_own_ranks(torch_cuda):
     assert "step_frac" in d["roofline"]
 
 
+def test_c_caller_of_the_delivery(torch_cuda, orc, tmp_path):
+    """tests/delivery_main.c: a main.c-style caller in plain C (no HIP headers) drives m1v_delivery_* — five batches of
+    different synthetic frames, every batch's records copied to pinned host memory under the next batch's encode and
+    appended to a file.  The file is the oracle's stream of the same 5 x n frames."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "delivery_main")
+    lib_dir = os.path.join(root, "ec504_imageencoder_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "delivery_main.c"), "-o", exe,
+                    "-L" + lib_dir, "-lencoder", "-Wl,-rpath," + lib_dir], check=True)
+    W, H, n, batches = 352, 288, 4, 5
+    out = str(tmp_path / "v.mpeg")
+    p = subprocess.run([exe, str(W), str(H), str(n), str(batches), out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    frames = orc.synth_frames(n * batches, W, H, seed=504)
+    want = orc.encode_sequence(frames, n * batches, W, H, 12, orc.MODE_FULL)
+    assert open(out, "rb").read() == want
+
+
 def test_host_delivery_overlapped_with_the_next_encode(torch_cuda, orc):
     """HostDelivery: batch k's records travel to pinned host memory on a side stream while batch k+1 encodes.  Five
     batches of DIFFERENT frames through two buffers: what arrives on the host is the oracle's stream, every time."""
