@@ -34,12 +34,24 @@
 // SIMDs).  Hence the one-job-per-wave prologue, scalar bases with 32-bit offsets, and four words per lane.
 constexpr unsigned long long kCtrBitsMask = (1ull << 40) - 1; // strip_ctr: bits of the strip; above: tile rows that have arrived
 constexpr int kCtrCountShift = 40;
-constexpr int kAsmThreads = 256;
+#ifndef M1V_ASM_THREADS
+#define M1V_ASM_THREADS 256
+#endif
+constexpr int kAsmThreads = M1V_ASM_THREADS; // 256, 128 or 64: the prologue's four jobs are dealt to the waves there are
+constexpr int kAsmWaves = kAsmThreads / 64;
+#ifndef M1V_ASM_CHUNK
+#define M1V_ASM_CHUNK 256
+#endif
+constexpr int kAsmChunk = M1V_ASM_CHUNK;     // segments placed at a time (one wave scans them in blocks of 64)
+constexpr int kAsmScanBlocks = kAsmChunk / 64;
 constexpr int kAsmMaxGroup = 16;
-constexpr int kAsmImageBytes = 14336; // LDS image of a group's output bytes: with the placement table 18.3 KB = eight workgroups per CU
+#ifndef M1V_ASM_IMAGE_BYTES
+#define M1V_ASM_IMAGE_BYTES 14336
+#endif
+constexpr int kAsmImageBytes = M1V_ASM_IMAGE_BYTES; // LDS image of a group's output bytes: with the placement table 18.3 KB = eight workgroups per CU
 // LDS words behind the image: [0..1] frame offset (u64), [2] bytes in front of the group, [3] bytes of the frame's strips,
 // [4] bytes of the group; from word 16: placement of <= 256 segments (16 bytes each)
-constexpr int kAsmPlace = 16, kAsmFixedWords = kAsmPlace + 4 * kAsmThreads;
+constexpr int kAsmPlace = 16, kAsmFixedWords = kAsmPlace + 4 * kAsmChunk;
 
 struct AssembleArgs {
     int n_frames, n_strips, segs; // segs = segments per strip
@@ -131,12 +143,12 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     // Destination bits of segments [c0, c0 + 256) -> place[]: one wave, four blocks of 64, loads first.  A strip's padding (zero
     // bits up to a byte, encoder.h:442-443) rides on its last segment, so the scan runs through strip boundaries.
     auto scan_chunk = [&](int c0, uint32_t &carry) {
-        uint2 sg[4];
-        unsigned long long ctr[4];
-        bool last[4];
-        const int blocks = min(4, (nseg - c0 + kWave - 1) / kWave); // uniform
+        uint2 sg[kAsmScanBlocks];
+        unsigned long long ctr[kAsmScanBlocks];
+        bool last[kAsmScanBlocks];
+        const int blocks = min(kAsmScanBlocks, (nseg - c0 + kWave - 1) / kWave); // uniform
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < kAsmScanBlocks; k++) {
             if (k >= blocks) break;
             const int q = min(c0 + 64 * k + lane, nseg - 1), j = (int)udiv((uint32_t)q, a.div_segs), t = q - j * T;
             last[k] = t == T - 1;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
             ctr[k] = ctr_f[s0 + j];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < kAsmScanBlocks; k++) {
             if (k >= blocks) break;
             const int q = c0 + 64 * k + lane;
             const uint32_t bits = q < nseg ? sg[k].x : 0u;
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     //      trip's source words here, in front of the barrier — their addresses need the segment table only, not the scan — was
     //      tried: the workgroup's chain stays segment entry -> source word -> image -> store, 7.8 us against 7.6.) ----
     uint32_t carry = 0; // wave 2: destination bit of the next chunk's first segment
-    if (wave == 0) {
+    if (wave == 0 % kAsmWaves) {
         unsigned long long acc = 0; // where the frame starts: 48 bytes of headers and trailer + its strips, for every frame in front
         for (int i0 = 0; i0 < f; i0 += 8 * kWave) { // eight loads in flight per lane: one trip up to 512 frames
             unsigned long long v[8];
@@ -183,7 +195,8 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         // (a lane's sum stays far below 2^56: two 32-bit reductions)
         const uint32_t lo = wave_sum_u32((uint32_t)acc & 0xffffffu), hi = wave_sum_u32((uint32_t)(acc >> 24));
         if (lane == 0) *reinterpret_cast<unsigned long long *>(fixed) = ((unsigned long long)hi << 24) + lo;
-    } else if (wave == 1) {
+    }
+    if (wave == 1 % kAsmWaves) {
         uint32_t before = 0, payload = 0; // bytes of the frame's strips: below 4 GiB (m1v_create bounds the frame)
         for (int t0 = 0; t0 < a.n_strips; t0 += 2 * kWave) {
             const unsigned long long c0 = ctr_f[min(t0 + lane, a.n_strips - 1)], c1 = ctr_f[min(t0 + kWave + lane, a.n_strips - 1)];
@@ -203,7 +216,8 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
         }
         if (lane == 15) fixed[4] = group_incl;
         if (f < a.next_frames && lane < ns) a.next_strip_ctr[(size_t)f * a.n_strips + s0 + lane] = 0ull;
-    } else if (wave == 2) {
+    }
+    if (wave == 2 % kAsmWaves) {
         scan_chunk(0, carry);
     }
     clear_image(cap_bytes);
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
     ASTAMP(0);
 
     // ---- housekeeping (wave 3 of the frame's first group): header, trailer, sizes, total, status; the next batch's counters ----
-    if (blockIdx.x == 0 && wave == 3) {
+    if (blockIdx.x == 0 && wave == 3 % kAsmWaves) {
         if (fits) frame_header_and_trailer(a.tab, a.out, fo, fs, a.first_index + f, lane);
         if (lane == 0) {
             if (f < a.next_frames) a.next_frame_bytes[f] = 0ull;
@@ -319,12 +333,12 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(AssembleArgs a) {
             clear_image(pass_bytes);
             carry = 0;
         }
-        for (int c0 = 0; c0 < nseg; c0 += kAsmThreads) {
+        for (int c0 = 0; c0 < nseg; c0 += kAsmChunk) {
             if (pass0 != 0 || c0 != 0) { // (the first chunk of the first pass was placed in the prologue)
-                if (wave == 2) scan_chunk(c0, carry);
+                if (wave == 2 % kAsmWaves) scan_chunk(c0, carry);
                 __syncthreads();
             }
-            const int cnt = min(kAsmThreads, nseg - c0);
+            const int cnt = min(kAsmChunk, nseg - c0);
             for (int e0 = 0; e0 < cnt; e0 += per_trip * U) {
                 AsmWords4 cur[U];
                 load_trip(cur, e0, cnt, word0);
