@@ -180,11 +180,35 @@ def cpu_baseline(W, H, qf, seed, gpu_head=None, budget_s=10.0):
     return out
 
 
+def _code_only(text):
+    """The source text without comments and without whitespace differences: what the compiler sees.  The PMC record's hash is
+    taken over this, so that a comment edit does not make the committed counters look stale."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                      # string / character literal: copied verbatim
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(" ".join(line.split()) for line in "".join(out).splitlines() if line.strip())
+
+
 def _pmc_sources_sha256(sources):
     import hashlib
     h = hashlib.sha256()
     for f in sources:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        h.update(_code_only(open(os.path.join(ROOT, f), encoding="utf-8").read()).encode("utf-8"))
     return h.hexdigest()
 
 

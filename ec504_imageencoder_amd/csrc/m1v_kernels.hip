@@ -1,15 +1,18 @@
 // ec504_imageencoder_amd/csrc/m1v_kernels.hip — MI355X (gfx950 / CDNA4) kernels and the C-ABI of
-// include/mpeg1_hip.h.  Written for gfx950 only: 64-wide waves, LDS-staged bit packing, 5 workgroups/CU.
+// include/mpeg1_hip.h.  Written for gfx950 only: 64-wide waves, LDS-staged bit packing, 5 waves per SIMD.
 //
 // Data layout in HBM
 //   input    n_frames x (H x W x C) interleaved u8, as the reference's Image::data (jpeg_handler.h:6-11)
-//   scratch  one slot per (frame, strip) of worst-case size; a strip = 16-pixel-wide COLUMN of
-//            macroblocks (encoder.h:238 iterates x outermost) and is byte aligned (encoder.h:442), so
-//            strips are independent units of bit packing
+//   scratch  one compact slot per unit of the encode kernel (a tile of 8 strips x 4 macroblock rows, or a run of 256 blocks)
+//            + an overflow arena of worst-case slots; a strip = 16-pixel-wide COLUMN of macroblocks (encoder.h:238
+//            iterates x outermost) and is byte aligned (encoder.h:442), so strips are independent units of bit packing;
+//            a segment table (bits, where) per (frame, segment, strip); per-strip bit counters, per-frame byte totals
 //   output   contiguous frame records  PKT SEQ GOP PIC strips 00000000  (encoder.h:196-458)
 //
 // Kernels
-//   k_encode_dense    the hot kernel (pictures whose strips hold >= 64 blocks).  A frame's blocks, in
+//   k_encode_tiles    (m1v_tiles.h) the encode kernel of every 3-channel picture: a workgroup per tile of 8 strips x 4
+//                     macroblock rows, pixels in as whole 128-byte lines by LDS-DMA, one lane per 8x8 block
+//   k_encode_dense    the run kernel (4-channel pictures; round 2's hot kernel).  A frame's blocks, in
 //                     stream order, are cut into runs of T consecutive blocks (default 256); one
 //                     workgroup per (frame, run), one LANE per 8x8 block (Y0..Y3, Cb, Cr of each
 //                     macroblock down the strip).  Per lane: 8 rows x 24 B of RGB -> component (three
@@ -21,10 +24,9 @@
 //                     OR-ed into an LDS image of the run (<= 2 byte-aligned strip segments) and stored
 //                     once.  Workgroups are dealt to XCDs so one frame's runs share an L2.
 //   k_encode_strips   one 64-lane workgroup per (frame, strip) for small pictures (< 64 blocks/strip)
-//   k_dense_frame_layout / k_frame_layout   per frame: strip bit/byte counts -> offsets
-//   k_frame_offsets   exclusive scan of frame sizes
-//   k_gather_segments (m1v_tiles.h) / k_gather   strips -> final positions (funnel shift of the run / tile segments),
-//                     frame headers, 16-bit length back-patch, trailer
+//   k_dense_frame_layout   run kernel only: run metadata -> segment table, strip bit counts, frame bytes
+//   k_assemble        (m1v_assemble.h) ONE launch behind every encode kernel: frame and strip offsets, the strips' segments
+//                     at their final bit positions, frame headers, 16-bit length back-patch, trailer, sizes, status
 //   k_coefficients    FDCT+quant+zigzag only (BASELINE config 2)
 //   k_convert, k_subsample, k_synth   plane conversion / 4:2:0 / synthetic input
 //
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(kWave) void k_encode_strips(EncodeArgs a) {
 // into runs of T consecutive blocks, one workgroup (T lanes, no idle lane) per run.  T <= blocks per
 // strip, so a run touches at most two strips: segment 0 (lanes < nA) continues or starts strip s0,
 // segment 1 (lanes >= nA) starts strip s0+1.  Each segment is packed on its own from a word boundary of
-// the workgroup's image (with the 38-bit slice header in front when it starts a strip); k_gather_segments
+// the workgroup's image (with the 38-bit slice header in front when it starts a strip); k_assemble
 // later concatenates the segments of a strip with the necessary bit shift.
 struct DenseArgs {
     Geometry g;
@@ -965,7 +967,7 @@ struct DenseArgs {
                             // arena: arena_slots x run_cap, handed out by an atomic counter to the runs that build in global memory
     uint32_t *run_meta;     // [frame][run][4]: bits of segment 0, bits of segment 1, first word of segment 1, where the run's
                             // bytes are (offset from `scratch` in 4-byte words)
-    uint32_t *arena_next;   // the counter (reset by k_frame_offsets of the same batch)
+    uint32_t *arena_next;   // the counter (cleared by the assemble kernel of the batch before)
     uint32_t slot_bytes, arena_slots;
     unsigned long long arena_off; // byte offset of the arena inside scratch
     uint32_t *status;

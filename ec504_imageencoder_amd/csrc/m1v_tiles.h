@@ -24,7 +24,7 @@
 // Bits.  A tile holds 8 strip SEGMENTS (24 consecutive blocks of the strip's stream each).  Lanes write their block's
 // bit count to LDS in emission order; after ONE barrier every wave scans all 192 counts itself (no second barrier),
 // segments start on word boundaries of the tile's LDS image, and the tile records (bits, where) per segment;
-// k_tile_layout / k_gather_segments concatenate a strip's segments (encoder.h:442-445).
+// k_assemble (m1v_assemble.h) concatenates a strip's segments (encoder.h:442-445).
 
 constexpr int kTileStrips = 8, kTileMbRows = 4;
 constexpr int kTileThreads = kTileStrips * kTileMbRows * 6; // 192

@@ -19,10 +19,12 @@ SOURCES = ["ec504_imageencoder_amd/csrc/m1v_kernels.hip", "ec504_imageencoder_am
 
 
 def source_sha256():
-    h = hashlib.sha256()
-    for s in SOURCES:
-        h.update(open(os.path.join(ROOT, s), "rb").read())
-    return h.hexdigest()
+    """bench.py's own hash (over the sources without comments and whitespace differences), so that both sides agree."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._pmc_sources_sha256(SOURCES)
 
 
 def parse(path):
