@@ -245,6 +245,63 @@ def test_host_delivery_retries_a_batch_that_ran_out_of_scratch(torch_cuda, orc):
     enc.close()
 
 
+def test_step_pipeline_retry_with_the_real_encoder(torch_cuda, orc):
+    """The N > 1 step loop (sharding.StepPipeline, as bench.py --backend gloo drives it: blobs staged through pinned host memory)
+    with the REAL encoder as producer, world 1: a forced tiny LDS image makes the first batch run out of overflow scratch
+    (M1V_STATUS_SCRATCH travels with the byte count), the rank reserves the worst case and encodes the same frames again, and
+    what is gathered for every step is the oracle's stream."""
+    import socket
+    import torch.distributed as dist
+    from ec504_imageencoder_amd.sharding import StepPipeline
+    torch = torch_cuda
+    W, H, n, steps = 1280, 720, 12, 4
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        enc = _enc(W, H, max_frames=n)
+        enc.debug_set_lds_words(8)
+        cap = enc.default_out_capacity(n)
+        outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        metas = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(2)]
+        sizes = torch.empty(n, dtype=torch.int64, device="cuda")
+        h_outs = [torch.empty(cap, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        h_metas = [torch.zeros(2, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+        batches = [enc.synth(n, seed=300 + k) for k in range(steps)]
+        state = {"step": 0, "held": {}}
+
+        def encode(b, k=None):
+            k = state["step"] if k is None else k
+            state["held"][b] = k
+            enc.encode(batches[k], 100 * k, out=outs[b], sizes=sizes, meta=metas[b])
+            h_metas[b].copy_(metas[b], non_blocking=True)
+            h_outs[b].copy_(outs[b], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            if k == state["step"]:
+                state["step"] += 1
+
+        def retry(b):
+            enc.reserve_scratch(True)
+            encode(b, state["held"][b])
+
+        host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        pipe = StepPipeline(encode, h_outs, h_metas, 1, 0, transport="host", host_buffer=host, retry=retry)
+        got = []
+        for k in range(steps):
+            pipe.step()
+            if pipe.last_counts is not None and len(got) < k:
+                got.append(bytes(host[:pipe.last_counts[0]].numpy()))
+        pipe.fence()
+        got.append(bytes(pipe.result().numpy()))
+        assert pipe.retries >= 1
+        wants = [orc.encode_frames(b.cpu().numpy(), n, W, H, 100 * k, 12, orc.MODE_FULL)[0] for k, b in enumerate(batches)]
+        assert got == wants
+        enc.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bench_starts_its_own_ranks(torch_cuda):
     """`python bench.py --gpus 2` as the driver runs it (no torchrun around it): bench.py starts torch.distributed.run as a child
     and prints ONE JSON line with n_gpus 2.  Rehearsal on this one-GPU box: gloo, both ranks on cuda:0."""
